@@ -1,0 +1,167 @@
+/*
+ * mmsa.h -- C ABI of libmmsa_hip.so: hand-written gfx950 (MI355X) kernels for the CNN multimodal sentiment model
+ * and its log-mel front end.
+ *
+ * The reference (suedaakkoc/multimodal-sentiment-analysis) is pure Python on torch.nn and has no FFI; the entry
+ * points below are what a binding for its hot path needs, one per fused operation.  Each comment cites the
+ * reference lines (relative to "CNN implementation/") whose arithmetic the entry point performs.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory unless the name ends in _host or the comment says "host";
+ *   - fp32 everywhere, token ids / labels / num_batches_tracked are int64 (long long);
+ *   - activations are channels-last [B][H][W][C]; weights arrive in the reference's layouts;
+ *   - `stream` is a hipStream_t (0 = default stream); kernels are only enqueued, never synchronised;
+ *   - return value: 0 on success, MMSA_ERR_ARG (-1) for rejected arguments (nothing was launched),
+ *     MMSA_ERR_LAUNCH (-2) if HIP reported a launch error;
+ *   - the library allocates no device memory: scratch comes from the caller, sized by the *_floats helpers;
+ *   - entry points are stateless and re-entrant; two calls that share output or scratch buffers must be ordered
+ *     by the caller (same stream).
+ */
+#ifndef MMSA_H
+#define MMSA_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMSA_OK 0
+#define MMSA_ERR_ARG (-1)
+#define MMSA_ERR_LAUNCH (-2)
+#define MMSA_ERR_LIMIT (-3)
+
+#define MMSA_API __attribute__((visibility("default")))
+
+/* Dense-layer epilogues (mmsa_dense_fwd / mmsa_dense_bwd). */
+#define MMSA_EPI_NONE 0     /* y = x W^T + b                                              */
+#define MMSA_EPI_LN_RELU 1  /* y = relu(LayerNorm(x W^T + b))   multimodal_model.py:237-249,395-401 */
+#define MMSA_EPI_RELU_LN 2  /* y = LayerNorm(relu(x W^T + b))   multimodal_model.py:382-388          */
+#define MMSA_EPI_RELU 3     /* y = relu(x W^T + b)                                        */
+
+/* ---- log-mel front end: preprocess.py:151-168 (pad/trim, MelSpectrogram, AmplitudeToDB, normalize, NaN scrub)
+ *      and :111-123 (z-score, unbiased std, clamp +-6). ------------------------------------------------------- */
+/* host helper: periodic Hann window [1024], FFT twiddles tw512 [256][2], tw1024 [513][2] (cos, -sin), in double */
+MMSA_API int mmsa_logmel_tables_host(float* window_host, float* tw512_host, float* tw1024_host);
+/* wave: [batch] rows of n_valid samples (row stride wave_stride floats) -> out [batch][1][64][1 + n_target/512].
+ * melfb [513][64] and melrange [64][2] (first bin, one past last bin with weight) describe the filterbank. */
+MMSA_API int mmsa_logmel_fwd(const float* wave, long wave_stride, int n_valid, int n_target, int batch,
+                             const float* window, const float* tw512, const float* tw1024, const float* melfb,
+                             const int* melrange, float top_db, float* out, void* stream);
+
+/* ---- convolutions as implicit GEMM on fp32 MFMA: multimodal_model.py:48-59,64-68 (ResidualBlock convs and 1x1
+ *      shortcut), :152-155,188 (text Conv1d); backward = autograd of the same (multimodal_train.py:192). ------ */
+/* w [Cout][Cin][ntaps] -> fwd [ntaps][Cout][Cin] and/or dgrad [ntaps][Cin][Cout] (either may be null) */
+MMSA_API int mmsa_conv_pack_weights(const float* w, float* fwd, float* dgrad, int Cout, int Cin, int ntaps,
+                                    void* stream);
+/* tile height the forward kernel uses for this geometry; statistics rows = B * ceil(H*W / tile height) */
+MMSA_API int mmsa_conv_tile_rows(int B, int H, int W, int Cout);
+/* Y[B,H,W,Cout] (= or +=) sum_t X[b, h+dh[t], w+dw[t], :] . Wp[t][:, :]; reads outside the image are zero.
+ * dh/dw are host arrays.  stats (optional): [B*tiles][2][Cout] per-tile column sums and sums of squares. */
+MMSA_API int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* stats, int B, int H, int W, int Cin,
+                           int Cout, int ntaps, const int* dh_host, const int* dw_host, int accumulate, void* stream);
+MMSA_API long mmsa_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int ntaps, int* nsplit_host);
+/* dW[Cout][Cin][ntaps] (= or +=) sum_{b,h,w<w_valid} X[b,h+dh,w+dw,cin] * dY[b,h,w,cout] */
+MMSA_API int mmsa_conv_wgrad(const float* X, const float* dY, float* dW, float* workspace, int B, int H, int W,
+                             int w_valid, int Cin, int Cout, int ntaps, const int* dh_host, const int* dw_host,
+                             int accumulate, void* stream);
+
+/* ---- audio branch, bandwidth-bound parts: multimodal_model.py:78-83 (stem), :27-42 (SEBlock), :64-70
+ *      (ResidualBlock tail), :87-96,118-127 (pools, global average). ----------------------------------------- */
+/* stem Conv2d(1,32,3,pad 1,bias): per-row partial sums of the conv output, partial [B*H][2][32] */
+MMSA_API int mmsa_stem_stats(const float* x, const float* w, const float* bias, float* partial, int B, int H, int W,
+                             void* stream);
+/* stem conv + BN (coeff [4][32]) + ReLU + MaxPool2d(2) -> out [B][H/2][W/2][32] */
+MMSA_API int mmsa_stem_apply_pool(const float* x, const float* w, const float* bias, const float* coeff, float* out,
+                                  int B, int H, int W, void* stream);
+/* stem backward from the pooled gradient; scratch >= B*(H/2)*384 + 64 floats */
+MMSA_API int mmsa_stem_bwd(const float* x, const float* w, const float* bias, const float* coeff, const float* dout,
+                           float* dW, float* dbias, float* dgamma, float* dbeta, float* scratch, int B, int H, int W,
+                           int training, void* stream);
+/* BatchNorm coefficients [4][C] = mean, invstd, scale, shift from partial sums [rows][2][C] (training; also updates
+ * running_mean/var with momentum and increments *nbt) or from the running statistics (eval).
+ * bsum (optional) [B][C]: per-utterance sums of the raw input (rows = B * tiles_per_img). */
+MMSA_API int mmsa_bn_finalize(const float* partial, int rows, int tiles_per_img, double count, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, long long* nbt,
+                              float momentum, float eps, int training, float* coeff, float* bsum, int C, void* stream);
+MMSA_API int mmsa_bn_relu_apply(const float* x, const float* coeff, float* y, long npos, int C, void* stream);
+/* squeeze-excite gate: gap = BN(mean_hw raw), hid = relu(W1 gap), gate = sigmoid(W2 hid) */
+MMSA_API int mmsa_se_gate(const float* bsum, const float* coeff, const float* W1, const float* W2, int HW, float* gap,
+                          float* hid, float* gate, int B, int C, int Ch, void* stream);
+/* out[B,H/2,W/2,C] = maxpool2( relu( BN2(c2) * gate + BN_s(sc) ) ) */
+MMSA_API int mmsa_res_gate_relu_pool(const float* c2, const float* sc, const float* coeff2, const float* coeffs,
+                                     const float* gate, float* out, int B, int H, int W, int C, void* stream);
+MMSA_API int mmsa_gap_fwd(const float* x, float* out, int B, int P, int C, void* stream);
+MMSA_API int mmsa_gap_bwd(const float* dout, float* dx, int B, int P, int C, void* stream);
+MMSA_API long mmsa_resblock_bwd_scratch_floats(int B, int H, int W, int C);
+/* backward of pool + ReLU + residual add + SE + bn2 / shortcut BN: dout -> d_c2, d_sc and parameter gradients */
+MMSA_API int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const float* sc, const float* coeff2,
+                                  const float* coeffs, const float* gate, const float* hid, const float* gap,
+                                  const float* bsum, const float* W1, const float* W2, float* d_c2, float* d_sc,
+                                  float* dgamma2, float* dbeta2, float* dgammas, float* dbetas, float* dW1, float* dW2,
+                                  float* scratch, int B, int H, int W, int C, int training, void* stream);
+MMSA_API long mmsa_bn_relu_bwd_scratch_floats(long npos, int C);
+/* in place: gradient w.r.t. relu(BN(c1)) -> gradient w.r.t. c1; also dgamma, dbeta */
+MMSA_API int mmsa_bn_relu_bwd(float* dh, const float* c1, const float* coeff, float* dgamma, float* dbeta,
+                              float* scratch, long npos, int C, int training, void* stream);
+
+/* ---- text branch: multimodal_model.py:149,179 (embedding gather, bit-exact), :186-197 (ReLU, max over time). */
+MMSA_API int mmsa_embedding_gather(const long long* ids, const float* table, float* out, long ntok, int E, long vocab,
+                                   int* err, void* stream);
+MMSA_API int mmsa_bias_relu_maxtime(const float* y, const float* bias, float* feat, int* arg, int B, int L, int Lout,
+                                    int F, int ldf, void* stream);
+/* sparse backward of conv + ReLU + max over time + gather; ksize/feat_off/wp/dW/dbias are host arrays
+ * (wp/dW/dbias: host arrays of device pointers); dtable is accumulated into; rows == padding_idx get nothing */
+MMSA_API int mmsa_text_bwd(const float* dfeat, const float* feat, const int* arg, const float* emb,
+                           const long long* ids, int nconv, const int* ksize_host, const int* feat_off_host,
+                           const float* const* wp_host, float* const* dW_host, float* const* dbias_host, float* dtable,
+                           int B, int L, int E, int F, int ldf, long padding_idx, void* stream);
+
+/* ---- fusion head and classifiers: multimodal_model.py:202-225, :228-285, :365-404, :448-454. ---------------- */
+MMSA_API int mmsa_dense_fwd(const float* X, int ldx, const float* W, const float* bias, const float* gamma,
+                            const float* beta, float* Y, int ldy, float* pre, float* stats, int B, int K, int N,
+                            int epilogue, float drop_p, unsigned long long seed, void* stream);
+MMSA_API int mmsa_dense_bwd(const float* dY, int ldy, const float* X, int ldx, const float* pre, const float* stats,
+                            const float* W, const float* gamma, const float* beta, float* dPre, float* dLn, float* dX,
+                            int lddx, float* dW, float* db, float* dgamma, float* dbeta, int B, int K, int N,
+                            int epilogue, float drop_p, unsigned long long seed, int accumulate_dx, void* stream);
+/* y = LayerNorm(x) * scale[0] * keep[0]   (keep optional: the modality-dropout switch, :264-268) */
+MMSA_API int mmsa_ln_scale_fwd(const float* x, const float* gamma, const float* beta, const float* scale,
+                               const float* keep, float* y, int ldy, float* stats, int B, int N, void* stream);
+MMSA_API int mmsa_ln_scale_bwd(const float* dy, int ldy, const float* x, const float* gamma, const float* beta,
+                               const float* scale, const float* keep, const float* stats, float* dx, float* dgamma,
+                               float* dbeta, float* dscale, float* scratch, int B, int N, void* stream);
+/* (w0,w1) = softmax(att[b]); fused = P[:, :Hd]*w0 + P[:, Hd:]*w1   (:275-283) */
+MMSA_API int mmsa_fusion_mix_fwd(const float* P, const float* att, float* wts, float* fused, int B, int Hd,
+                                 void* stream);
+MMSA_API int mmsa_fusion_mix_bwd(const float* dfused, const float* P, const float* wts, float* dP, float* datt, int B,
+                                 int Hd, void* stream);
+/* probabilities, mean cross-entropy and d(loss)/d(logits) = (p - onehot)/B   (:449-454) */
+MMSA_API int mmsa_softmax_ce(const float* logits, const long long* labels, float* probs, float* loss, float* dlogits,
+                             int B, int C, void* stream);
+/* BatchNorm1d + ReLU (+dropout) of the audio-only classifier (:369-371,373-375) */
+MMSA_API int mmsa_bn1d_relu_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, long long* nbt, float momentum, float eps, int training, float* y,
+                                float* coeff, int B, int N, float drop_p, unsigned long long seed, void* stream);
+MMSA_API int mmsa_bn1d_relu_bwd(const float* dy, const float* x, const float* coeff, float* dx, float* dgamma,
+                                float* dbeta, int B, int N, int training, float drop_p, unsigned long long seed,
+                                void* stream);
+MMSA_API int mmsa_dropout(const float* x, float* y, long n, float drop_p, unsigned long long seed, void* stream);
+
+/* ---- loss regulariser, clipping, optimiser: multimodal_model.py:456-462; multimodal_train.py:194-195,481-485. */
+MMSA_API int mmsa_param_norms(const float* p, const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
+                              int nchunks, const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* tnorm,
+                              float* sum_out, void* stream);
+MMSA_API int mmsa_l2_grad_add(float* g, const float* p, const float* tnorm, float lambda, const long long* chunk_off,
+                              const int* chunk_len, const int* chunk_tensor, int nchunks, void* stream);
+MMSA_API int mmsa_grad_norm(const float* g, const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
+                            int nchunks, const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* state,
+                            void* stream);
+/* state (8 floats): 0 step, 1 1-beta1^t, 2 sqrt(1-beta2^t), 3 clip coefficient, 4 total grad norm, 5 sum of norms */
+MMSA_API int mmsa_adamw_step(float* p, const float* g, float* m, float* v, long n, float* state, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, float max_norm, int do_clip, void* stream);
+MMSA_API int mmsa_scale_by_state(float* g, long n, const float* state, int idx, void* stream);
+MMSA_API int mmsa_scalar_axpy(float* dst, const float* a, const float* b, float alpha, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMSA_H */

@@ -1,0 +1,890 @@
+// Bandwidth-bound kernels of the audio branch (everything that is not a dense contraction):
+// the 1->32 channel stem, BatchNorm statistics/coefficients, squeeze-excite gates, the fused
+// gate * BN + shortcut BN + ReLU + 2x2 max-pool, global average pooling, and all their backward passes.
+//
+// Reference semantics: `CNN implementation/multimodal_model.py:27-42` (SEBlock), `:45-70` (ResidualBlock),
+// `:78-83,118-129` (stem, pools, global pool).  BatchNorm follows torch defaults: eps 1e-5, momentum 0.1,
+// biased variance for normalisation, unbiased for the running estimate.
+//
+// Layout: activations channels-last [B][H][W][C]; BN coefficient tables are [4][C] = mean, 1/sqrt(var+eps),
+// scale = gamma*invstd, shift = beta - mean*scale.  Every cross-workgroup reduction is two-stage (per-block
+// partials, then a fixed-order sum), so results do not change from run to run.
+#include "mmsa_common.h"
+
+namespace {
+
+constexpr int STEM_C = 32;
+
+// ------------------------------------------------------------------------------------------------ stem
+// conv value at column w of the row triple staged in `rows` (each row has a zero at index 0 and W+1)
+__device__ __forceinline__ float stem_conv(const float* r0, const float* r1, const float* r2, int w, const float* k,
+                                           float bias) {
+  float a = bias;
+  a = fmaf(k[0], r0[w], a); a = fmaf(k[1], r0[w + 1], a); a = fmaf(k[2], r0[w + 2], a);
+  a = fmaf(k[3], r1[w], a); a = fmaf(k[4], r1[w + 1], a); a = fmaf(k[5], r1[w + 2], a);
+  a = fmaf(k[6], r2[w], a); a = fmaf(k[7], r2[w + 1], a); a = fmaf(k[8], r2[w + 2], a);
+  return a;
+}
+
+template <int NROWS>
+__device__ __forceinline__ void stem_stage_rows(float* rows, int ldw, const float* xb, int h_first, int H, int W) {
+  for (int i = threadIdx.x; i < NROWS * ldw; i += blockDim.x) {
+    const int r = i / ldw, col = i - r * ldw;
+    const int h = h_first + r, w = col - 1;
+    float v = 0.f;
+    if (h >= 0 && h < H && w >= 0 && w < W) v = xb[h * W + w];
+    rows[i] = v;
+  }
+}
+
+// one block per input row (b,h): per-channel sum / sum of squares of the conv output
+__global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                         const float* __restrict__ bias, float* __restrict__ partial,
+                                                         int H, int W) {
+  extern __shared__ float sm[];
+  const int ldw = W + 2;
+  float* rows = sm;                 // [3][ldw]
+  float* red = sm + 3 * ldw;        // [8][2][32]
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  stem_stage_rows<3>(rows, ldw, x + (long)b * H * W, h - 1, H, W);
+  const int c = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  float k[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k[i] = wgt[c * 9 + i];
+  const float bs = bias[c];
+  __syncthreads();
+  float s = 0.f, q = 0.f;
+  for (int w = pl; w < W; w += 8) {
+    const float v = stem_conv(rows, rows + ldw, rows + 2 * ldw, w, k, bs);
+    s += v;
+    q = fmaf(v, v, q);
+  }
+  red[(pl * 2 + 0) * 32 + c] = s;
+  red[(pl * 2 + 1) * 32 + c] = q;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int which = threadIdx.x >> 5;
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) t += red[(p * 2 + which) * 32 + c];
+    partial[((long)blockIdx.x * 2 + which) * STEM_C + c] = t;
+  }
+}
+
+// one block per pooled row (b,h2): recompute conv, BN, ReLU, 2x2 max -> out[b][h2][w2][32]
+__global__ __launch_bounds__(256) void stem_apply_pool_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ coeff, float* __restrict__ out,
+                                                              int H, int W) {
+  extern __shared__ float sm[];
+  const int ldw = W + 2, H2 = H / 2, W2 = W / 2;
+  const int b = blockIdx.x / H2, h2 = blockIdx.x - b * H2;
+  stem_stage_rows<4>(sm, ldw, x + (long)b * H * W, 2 * h2 - 1, H, W);
+  const int c = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  float k[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k[i] = wgt[c * 9 + i];
+  const float bs = bias[c], sc = coeff[2 * STEM_C + c], sh = coeff[3 * STEM_C + c];
+  __syncthreads();
+  for (int w2 = pl; w2 < W2; w2 += 8) {
+    float m = 0.f;  // ReLU folded into the max
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float v = stem_conv(sm + i * ldw, sm + (i + 1) * ldw, sm + (i + 2) * ldw, 2 * w2 + j, k, bs);
+        m = fmaxf(m, fmaf(v, sc, sh));
+      }
+    out[(((long)b * H2 + h2) * W2 + w2) * STEM_C + c] = m;
+  }
+}
+
+// backward pass 1: route the pooled gradient to the window argmax (first maximum, as torch's max_pool2d),
+// gate by ReLU, accumulate sum(dz) and sum(dz * xhat) per channel.  partial[B*H2][2][32].
+__global__ __launch_bounds__(256) void stem_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                             const float* __restrict__ bias,
+                                                             const float* __restrict__ coeff,
+                                                             const float* __restrict__ dout,
+                                                             float* __restrict__ partial, int H, int W) {
+  extern __shared__ float sm[];
+  const int ldw = W + 2, H2 = H / 2, W2 = W / 2;
+  float* red = sm + 4 * ldw;
+  const int b = blockIdx.x / H2, h2 = blockIdx.x - b * H2;
+  stem_stage_rows<4>(sm, ldw, x + (long)b * H * W, 2 * h2 - 1, H, W);
+  const int c = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  float k[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k[i] = wgt[c * 9 + i];
+  const float bs = bias[c];
+  const float mean = coeff[c], istd = coeff[STEM_C + c], sc = coeff[2 * STEM_C + c], sh = coeff[3 * STEM_C + c];
+  __syncthreads();
+  float s1 = 0.f, s2 = 0.f;
+  for (int w2 = pl; w2 < W2; w2 += 8) {
+    float best = -INFINITY, bestconv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float v = stem_conv(sm + i * ldw, sm + (i + 1) * ldw, sm + (i + 2) * ldw, 2 * w2 + j, k, bs);
+        const float y = fmaxf(fmaf(v, sc, sh), 0.f);
+        if (y > best) { best = y; bestconv = v; }
+      }
+    if (best > 0.f) {
+      const float d = dout[(((long)b * H2 + h2) * W2 + w2) * STEM_C + c];
+      s1 += d;
+      s2 = fmaf(d, (bestconv - mean) * istd, s2);
+    }
+  }
+  red[(pl * 2 + 0) * 32 + c] = s1;
+  red[(pl * 2 + 1) * 32 + c] = s2;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int which = threadIdx.x >> 5;
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) t += red[(p * 2 + which) * 32 + c];
+    partial[((long)blockIdx.x * 2 + which) * STEM_C + c] = t;
+  }
+}
+
+// backward pass 2: dconv = scale*(dz - S1/N - xhat*S2/N) at every full-resolution position;
+// accumulate dW[c][tap] = sum dconv * x[pos+tap], dbias[c] = sum dconv.  partial[B*H2][32][10].
+__global__ __launch_bounds__(256) void stem_bwd_w_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ coeff,
+                                                         const float* __restrict__ dout, const float* __restrict__ s12,
+                                                         float inv_n, float* __restrict__ partial, int H, int W) {
+  extern __shared__ float sm[];
+  const int ldw = W + 2, H2 = H / 2, W2 = W / 2;
+  float* red = sm + 4 * ldw;  // [8][32][10]
+  const int b = blockIdx.x / H2, h2 = blockIdx.x - b * H2;
+  stem_stage_rows<4>(sm, ldw, x + (long)b * H * W, 2 * h2 - 1, H, W);
+  const int c = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  float k[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k[i] = wgt[c * 9 + i];
+  const float bs = bias[c];
+  const float mean = coeff[c], istd = coeff[STEM_C + c], sc = coeff[2 * STEM_C + c], sh = coeff[3 * STEM_C + c];
+  const float m1 = s12[c] * inv_n, m2 = s12[STEM_C + c] * inv_n;
+  __syncthreads();
+  float acc[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+  // columns: pooled windows cover w < 2*W2; a trailing odd column still receives the dense BN terms
+  const int ncol = (W + 1) / 2;
+  for (int w2 = pl; w2 < ncol; w2 += 8) {
+    float conv[2][2];
+    float best = -INFINITY;
+    int bi = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int w = 2 * w2 + j;
+        conv[i][j] = (w < W) ? stem_conv(sm + i * ldw, sm + (i + 1) * ldw, sm + (i + 2) * ldw, w, k, bs) : 0.f;
+        const float y = fmaxf(fmaf(conv[i][j], sc, sh), 0.f);
+        if (y > best) { best = y; bi = i * 2 + j; }
+      }
+    const bool pooled = w2 < W2;
+    const float d = (pooled && best > 0.f) ? dout[(((long)b * H2 + h2) * W2 + w2) * STEM_C + c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int w = 2 * w2 + j;
+        if (w < W) {
+          const float dz = (pooled && (i * 2 + j) == bi) ? d : 0.f;
+          const float xh = (conv[i][j] - mean) * istd;
+          const float dc = sc * (dz - m1 - xh * m2);
+          const float* r0 = sm + i * ldw + w;
+          acc[0] = fmaf(dc, r0[0], acc[0]); acc[1] = fmaf(dc, r0[1], acc[1]); acc[2] = fmaf(dc, r0[2], acc[2]);
+          acc[3] = fmaf(dc, r0[ldw], acc[3]); acc[4] = fmaf(dc, r0[ldw + 1], acc[4]);
+          acc[5] = fmaf(dc, r0[ldw + 2], acc[5]);
+          acc[6] = fmaf(dc, r0[2 * ldw], acc[6]); acc[7] = fmaf(dc, r0[2 * ldw + 1], acc[7]);
+          acc[8] = fmaf(dc, r0[2 * ldw + 2], acc[8]);
+          acc[9] += dc;
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 10; ++i) red[(pl * 32 + c) * 10 + i] = acc[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 320; i += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) t += red[p * 320 + i];
+    partial[(long)blockIdx.x * 320 + i] = t;
+  }
+}
+
+// sum partial[rows][320] (c*10+k) -> dW[32*9], dbias[32]
+__global__ __launch_bounds__(256) void stem_bwd_w_finalize_kernel(const float* __restrict__ partial, int rows,
+                                                                  float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ double red[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  double s = 0.0;
+  if (col < 320)
+    for (int r = w; r < rows; r += 4) s += (double)partial[(long)r * 320 + col];
+  red[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && col < 320) {
+    const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    const int c = col / 10, k = col - c * 10;
+    if (k < 9) dW[c * 9 + k] = (float)t; else db[c] = (float)t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm
+// partial: [rows][2][C] sums / sums of squares (rows = B * tiles, tiles of one image contiguous).
+// One block per 64 channels; lane = channel (coalesced), the 4 waves split the rows, double accumulation.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int tiles_per_img,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, long long* __restrict__ nbt,
+                                                          float momentum, float eps, int training,
+                                                          float* __restrict__ coeff, float* __restrict__ bsum, int C) {
+  __shared__ double red[2][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const bool cv = c < C;
+  double s = 0.0, q = 0.0;
+  if (cv && training) {
+    for (int r = w; r < rows; r += 4) {
+      s += (double)partial[((long)r * 2) * C + c];
+      q += (double)partial[((long)r * 2 + 1) * C + c];
+    }
+  }
+  red[0][w][lane] = s;
+  red[1][w][lane] = q;
+  __syncthreads();
+  if (w == 0 && cv) {
+    float mean, var;
+    if (training) {
+      const double ts = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+      const double tq = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+      const double m = ts / count;
+      double v = tq / count - m * m;
+      if (v < 0.0) v = 0.0;
+      mean = (float)m;
+      var = (float)v;
+      if (rmean) {
+        const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+      }
+    } else {
+      mean = rmean[c];
+      var = rvar[c];
+    }
+    const float istd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * istd;
+    coeff[c] = mean;
+    coeff[C + c] = istd;
+    coeff[2 * C + c] = sc;
+    coeff[3 * C + c] = beta[c] - mean * sc;
+  }
+  if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+  if (bsum && cv) {
+    const int B = rows / tiles_per_img;
+    for (int b = w; b < B; b += 4) {
+      float t = 0.f;
+      for (int i = 0; i < tiles_per_img; ++i) t += partial[(((long)b * tiles_per_img + i) * 2) * C + c];
+      bsum[(long)b * C + c] = t;
+    }
+  }
+}
+
+__global__ void bn_relu_apply_kernel(const f32x4* __restrict__ x, const float* __restrict__ coeff,
+                                     f32x4* __restrict__ y, long n4, int C) {
+  const int c4n = C >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const f32x4 v = x[i];
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(coeff + 2 * C + c);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(coeff + 3 * C + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = fmaxf(fmaf(v[k], sc[k], sh[k]), 0.f);
+    y[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ squeeze-excite
+// one block per utterance.  gap = scale*mean_hw(raw) + shift; hid = relu(W1 gap); gate = sigmoid(W2 hid)
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ bsum, const float* __restrict__ coeff,
+                                                      const float* __restrict__ W1, const float* __restrict__ W2,
+                                                      float inv_hw, float* __restrict__ gap, float* __restrict__ hid,
+                                                      float* __restrict__ gate, int C, int Ch) {
+  __shared__ float g[256];
+  __shared__ float hd[16];
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t < C) {
+    const float v = fmaf(coeff[2 * C + t], bsum[(long)b * C + t] * inv_hw, coeff[3 * C + t]);
+    g[t] = v;
+    gap[(long)b * C + t] = v;
+  }
+  __syncthreads();
+  const int lane = t & 63, w = t >> 6;
+  for (int j = w; j < Ch; j += 4) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a = fmaf(W1[(long)j * C + c], g[c], a);
+    a = wave_sum(a);
+    if (lane == 0) {
+      a = fmaxf(a, 0.f);
+      hd[j] = a;
+      hid[(long)b * Ch + j] = a;
+    }
+  }
+  __syncthreads();
+  if (t < C) {
+    float a = 0.f;
+    for (int j = 0; j < Ch; ++j) a = fmaf(W2[(long)t * Ch + j], hd[j], a);
+    gate[(long)b * C + t] = 1.0f / (1.0f + expf(-a));
+  }
+}
+
+// out[b][h2][w2][c] = max over the 2x2 window of relu( bn2(c2)*gate[b][c] + bn_s(sc) )
+__global__ void res_gate_relu_pool_kernel(const float* __restrict__ c2, const float* __restrict__ sc,
+                                          const float* __restrict__ coeff2, const float* __restrict__ coeffs,
+                                          const float* __restrict__ gate, float* __restrict__ out, int B, int H, int W,
+                                          int C) {
+  const int H2 = H / 2, W2 = W / 2, c4n = C >> 2;
+  const long total = (long)B * H2 * W2 * c4n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    long r = i / c4n;
+    const int w2 = (int)(r % W2); r /= W2;
+    const int h2 = (int)(r % H2);
+    const int b = (int)(r / H2);
+    const f32x4 s2 = *reinterpret_cast<const f32x4*>(coeff2 + 2 * C + c);
+    const f32x4 h2c = *reinterpret_cast<const f32x4*>(coeff2 + 3 * C + c);
+    const f32x4 ss = *reinterpret_cast<const f32x4*>(coeffs + 2 * C + c);
+    const f32x4 hs = *reinterpret_cast<const f32x4*>(coeffs + 3 * C + c);
+    const f32x4 gt = *reinterpret_cast<const f32x4*>(gate + (long)b * C + c);
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const long off = (((long)b * H + 2 * h2 + dy) * W + 2 * w2 + dx) * C + c;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(c2 + off);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(sc + off);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float z = fmaf(fmaf(a[k], s2[k], h2c[k]), gt[k], fmaf(s[k], ss[k], hs[k]));
+          m[k] = fmaxf(m[k], z);
+        }
+      }
+    *reinterpret_cast<f32x4*>(out + i * 4) = m;
+  }
+}
+
+__global__ void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int P, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  float s = 0.f;
+  for (int p = 0; p < P; ++p) s += x[((long)b * P + p) * C + c];
+  out[i] = s / (float)P;
+}
+
+__global__ void gap_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int B, int P, int C) {
+  const long total = (long)B * P * C;
+  const float inv = 1.0f / (float)P;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int b = (int)(i / ((long)P * C));
+    dx[i] = dout[(long)b * C + c] * inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ block backward
+// Pass A: dz (gradient w.r.t. the pre-ReLU sum z = bn2(c2)*gate + bn_s(sc)) routed through pool + ReLU, and
+// per-(b, chunk) partial sums A1 = sum dz, A2 = sum dz*c2, A3 = sum dz*sc.   partial[b][chunk][3][C].
+// Block: (C/4) channel quads x (1024/C) position lanes; each block covers `chunk` pooled positions of one image.
+__global__ __launch_bounds__(256) void res_pool_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ c2,
+                                                           const float* __restrict__ sc,
+                                                           const float* __restrict__ coeff2,
+                                                           const float* __restrict__ coeffs,
+                                                           const float* __restrict__ gate, float* __restrict__ dz,
+                                                           float* __restrict__ partial, int H, int W, int C, int chunk,
+                                                           int nchunks) {
+  extern __shared__ float red[];  // [planes][3][C]
+  const int c4n = C >> 2, planes = 256 / c4n;
+  const int q = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+  const int c = q * 4;
+  const int b = blockIdx.x / nchunks, ch = blockIdx.x - b * nchunks;
+  const int H2 = H / 2, W2 = W / 2, P2 = H2 * W2;
+  const f32x4 s2 = *reinterpret_cast<const f32x4*>(coeff2 + 2 * C + c);
+  const f32x4 h2c = *reinterpret_cast<const f32x4*>(coeff2 + 3 * C + c);
+  const f32x4 ss = *reinterpret_cast<const f32x4*>(coeffs + 2 * C + c);
+  const f32x4 hs = *reinterpret_cast<const f32x4*>(coeffs + 3 * C + c);
+  const f32x4 gt = *reinterpret_cast<const f32x4*>(gate + (long)b * C + c);
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+  const int pend = min((ch + 1) * chunk, P2);
+  for (int p2 = ch * chunk + pl; p2 < pend; p2 += planes) {
+    const int h2 = p2 / W2, w2 = p2 - h2 * W2;
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dout + ((long)b * P2 + p2) * C + c);
+    f32x4 av[4], sv[4];
+    long offs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      offs[k] = (((long)b * H + 2 * h2 + (k >> 1)) * W + 2 * w2 + (k & 1)) * C + c;
+      av[k] = *reinterpret_cast<const f32x4*>(c2 + offs[k]);
+      sv[k] = *reinterpret_cast<const f32x4*>(sc + offs[k]);
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float best = -INFINITY;
+      int bi = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float z = fmaf(fmaf(av[k][e], s2[e], h2c[e]), gt[e], fmaf(sv[k][e], ss[e], hs[e]));
+        const float y = fmaxf(z, 0.f);
+        if (y > best) { best = y; bi = k; }
+      }
+      if (best > 0.f) {
+        const float g = d[e];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k == bi) {
+            o[k][e] = g;
+            a2[e] = fmaf(g, av[k][e], a2[e]);
+            a3[e] = fmaf(g, sv[k][e], a3[e]);
+          }
+        a1[e] += g;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dz + offs[k]) = o[k];
+  }
+  float* mine = red + (long)pl * 3 * C;
+  *reinterpret_cast<f32x4*>(mine + c) = a1;
+  *reinterpret_cast<f32x4*>(mine + C + c) = a2;
+  *reinterpret_cast<f32x4*>(mine + 2 * C + c) = a3;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += 256) {
+    float t = 0.f;
+    for (int p = 0; p < planes; ++p) t += red[(long)p * 3 * C + i];
+    partial[((long)blockIdx.x) * 3 * C + i] = t;
+  }
+}
+
+// SE backward per utterance.  Outputs A[b][3][C] (chunk sums), du[b][C], dhp[b][Ch], dg[b][C].
+__global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ partial, int nchunks,
+                                                     const float* __restrict__ coeff2, const float* __restrict__ gate,
+                                                     const float* __restrict__ hid, const float* __restrict__ W1,
+                                                     const float* __restrict__ W2, float* __restrict__ A,
+                                                     float* __restrict__ du, float* __restrict__ dhp,
+                                                     float* __restrict__ dg, int C, int Ch) {
+  __shared__ float sdu[256];
+  __shared__ float sdh[16];
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t < C) {
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < nchunks; ++k)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) a[j] += partial[(((long)b * nchunks + k) * 3 + j) * C + t];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) A[((long)b * 3 + j) * C + t] = a[j];
+    const float ds = fmaf(coeff2[2 * C + t], a[1], coeff2[3 * C + t] * a[0]);   // sum dz * bn2(c2)
+    const float s = gate[(long)b * C + t];
+    const float u = ds * s * (1.f - s);
+    sdu[t] = u;
+    du[(long)b * C + t] = u;
+  }
+  __syncthreads();
+  const int lane = t & 63, w = t >> 6;
+  for (int j = w; j < Ch; j += 4) {
+    float a = 0.f;
+    for (int c = lane; c < C; c += 64) a = fmaf(W2[(long)c * Ch + j], sdu[c], a);
+    a = wave_sum(a);
+    if (lane == 0) {
+      a = hid[(long)b * Ch + j] > 0.f ? a : 0.f;
+      sdh[j] = a;
+      dhp[(long)b * Ch + j] = a;
+    }
+  }
+  __syncthreads();
+  if (t < C) {
+    float a = 0.f;
+    for (int j = 0; j < Ch; ++j) a = fmaf(W1[(long)j * C + t], sdh[j], a);
+    dg[(long)b * C + t] = a;
+  }
+}
+
+// Per-channel BN backward sums for bn2 and the shortcut BN, their affine gradients and the coefficient
+// tables of pass B:   d_c2 = P[b][c]*dz + Q[c]*c2 + R[b][c],   d_sc = Ps[c]*dz + Qs[c]*sc + Rs[c].
+// tab: P[B][C], R[B][C], then Q[C], Ps[C], Qs[C], Rs[C].
+__global__ void rb_bwd_coeff_kernel(const float* __restrict__ A, const float* __restrict__ gate,
+                                    const float* __restrict__ dg, const float* __restrict__ bsum,
+                                    const float* __restrict__ coeff2, const float* __restrict__ coeffs, int B, int C,
+                                    float hw, float* __restrict__ dgamma2, float* __restrict__ dbeta2,
+                                    float* __restrict__ dgammas, float* __restrict__ dbetas, float* __restrict__ tab,
+                                    int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean2 = coeff2[c], istd2 = coeff2[C + c], sc2 = coeff2[2 * C + c];
+  const float means = coeffs[c], istds = coeffs[C + c], scs = coeffs[2 * C + c];
+  double S1 = 0.0, S2 = 0.0, S1s = 0.0, S2s = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float a1 = A[((long)b * 3 + 0) * C + c], a2 = A[((long)b * 3 + 1) * C + c], a3 = A[((long)b * 3 + 2) * C + c];
+    const float s = gate[(long)b * C + c], g = dg[(long)b * C + c];
+    S1 += (double)(s * a1 + g);
+    S2 += (double)(s * (a2 - mean2 * a1) * istd2 + (g / hw) * (bsum[(long)b * C + c] - hw * mean2) * istd2);
+    S1s += (double)a1;
+    S2s += (double)((a3 - means * a1) * istds);
+  }
+  dgamma2[c] = (float)S2; dbeta2[c] = (float)S1;
+  dgammas[c] = (float)S2s; dbetas[c] = (float)S1s;
+  const float n = (float)B * hw;
+  // in eval mode BatchNorm is a fixed affine map: only the scale survives
+  const float m1 = training ? (float)S1 / n : 0.f, m2 = training ? (float)S2 / n : 0.f;
+  const float m1s = training ? (float)S1s / n : 0.f, m2s = training ? (float)S2s / n : 0.f;
+  float* P = tab;
+  float* R = tab + (long)B * C;
+  float* Q = tab + 2L * B * C;
+  Q[c] = -sc2 * istd2 * m2;
+  Q[C + c] = scs;                                   // Ps
+  Q[2 * C + c] = -scs * istds * m2s;                // Qs
+  Q[3 * C + c] = -scs * m1s + scs * istds * m2s * means;   // Rs
+  for (int b = 0; b < B; ++b) {
+    const float s = gate[(long)b * C + c], g = dg[(long)b * C + c];
+    P[(long)b * C + c] = sc2 * s;
+    R[(long)b * C + c] = sc2 * (g / hw - m1) + sc2 * istd2 * m2 * mean2;
+  }
+}
+
+// dW2[c][j] = sum_b du[b][c]*hid[b][j];  dW1[j][c] = sum_b dhp[b][j]*gap[b][c]
+__global__ void se_wgrad_kernel(const float* __restrict__ du, const float* __restrict__ hid,
+                                const float* __restrict__ dhp, const float* __restrict__ gap, float* __restrict__ dW1,
+                                float* __restrict__ dW2, int B, int C, int Ch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = C * Ch;
+  if (i < n) {  // dW2 [C][Ch]
+    const int c = i / Ch, j = i - c * Ch;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s = fmaf(du[(long)b * C + c], hid[(long)b * Ch + j], s);
+    dW2[i] = s;
+  } else if (i < 2 * n) {  // dW1 [Ch][C]
+    const int k = i - n;
+    const int j = k / C, c = k - j * C;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s = fmaf(dhp[(long)b * Ch + j], gap[(long)b * C + c], s);
+    dW1[k] = s;
+  }
+}
+
+// Pass B: d_c2 and d_sc from dz (d_sc may alias dz).
+__global__ void rb_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ c2,
+                                    const float* __restrict__ sc, const float* __restrict__ tab, float* __restrict__ dc2,
+                                    float* dsc, int B, long HW, int C) {
+  const int c4n = C >> 2;
+  const long total = (long)B * HW * c4n;
+  const float* P = tab;
+  const float* R = tab + (long)B * C;
+  const float* Q = tab + 2L * B * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const int b = (int)(i / (HW * c4n));
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dz + i * 4);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(c2 + i * 4);
+    const f32x4 s = *reinterpret_cast<const f32x4*>(sc + i * 4);
+    const f32x4 p = *reinterpret_cast<const f32x4*>(P + (long)b * C + c);
+    const f32x4 r = *reinterpret_cast<const f32x4*>(R + (long)b * C + c);
+    const f32x4 q = *reinterpret_cast<const f32x4*>(Q + c);
+    const f32x4 ps = *reinterpret_cast<const f32x4*>(Q + C + c);
+    const f32x4 qs = *reinterpret_cast<const f32x4*>(Q + 2 * C + c);
+    const f32x4 rs = *reinterpret_cast<const f32x4*>(Q + 3 * C + c);
+    f32x4 o1, o2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      o1[k] = fmaf(p[k], d[k], fmaf(q[k], a[k], r[k]));
+      o2[k] = fmaf(ps[k], d[k], fmaf(qs[k], s[k], rs[k]));
+    }
+    *reinterpret_cast<f32x4*>(dc2 + i * 4) = o1;
+    *reinterpret_cast<f32x4*>(dsc + i * 4) = o2;
+  }
+}
+
+// ReLU + BN backward statistics for bn1: g = dh * [bn1(c1) > 0]; partial[blocks][2][C] = sum g, sum g*xhat
+__global__ __launch_bounds__(256) void bn_relu_bwd_stats_kernel(const float* __restrict__ dh, const float* __restrict__ c1,
+                                                                const float* __restrict__ coeff,
+                                                                float* __restrict__ partial, long npos, int C,
+                                                                int pos_per_block) {
+  extern __shared__ float red[];  // [planes][2][C]
+  const int c4n = C >> 2, planes = 256 / c4n;
+  const int q = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+  const int c = q * 4;
+  const f32x4 mean = *reinterpret_cast<const f32x4*>(coeff + c);
+  const f32x4 istd = *reinterpret_cast<const f32x4*>(coeff + C + c);
+  const f32x4 scl = *reinterpret_cast<const f32x4*>(coeff + 2 * C + c);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(coeff + 3 * C + c);
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  const long pbeg = (long)blockIdx.x * pos_per_block;
+  long pend = pbeg + pos_per_block;
+  if (pend > npos) pend = npos;
+  for (long p = pbeg + pl; p < pend; p += planes) {
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dh + p * C + c);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(c1 + p * C + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float g = fmaf(x[k], scl[k], sh[k]) > 0.f ? d[k] : 0.f;
+      s1[k] += g;
+      s2[k] = fmaf(g, (x[k] - mean[k]) * istd[k], s2[k]);
+    }
+  }
+  float* mine = red + (long)pl * 2 * C;
+  *reinterpret_cast<f32x4*>(mine + c) = s1;
+  *reinterpret_cast<f32x4*>(mine + C + c) = s2;
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float t = 0.f;
+    for (int p = 0; p < planes; ++p) t += red[(long)p * 2 * C + i];
+    partial[(long)blockIdx.x * 2 * C + i] = t;
+  }
+}
+
+// sums the partial rows, writes dgamma/dbeta, s12 = [S1[C], S2[C]] and cb[3][C] = (scale, Q, R) with
+// d_x = [relu mask]*scale*dy + Q*x + R
+__global__ __launch_bounds__(256) void bn_bwd_coeff_kernel(const float* __restrict__ partial, int rows, double count,
+                                                           const float* __restrict__ coeff, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, float* __restrict__ s12,
+                                                           float* __restrict__ cb, int C, int training) {
+  __shared__ double red[2][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const bool cv = c < C;
+  double s = 0.0, q = 0.0;
+  if (cv)
+    for (int r = w; r < rows; r += 4) {
+      s += (double)partial[((long)r * 2) * C + c];
+      q += (double)partial[((long)r * 2 + 1) * C + c];
+    }
+  red[0][w][lane] = s;
+  red[1][w][lane] = q;
+  __syncthreads();
+  if (w == 0 && cv) {
+    const double S1 = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+    const double S2 = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+    if (dgamma) dgamma[c] = (float)S2;
+    if (dbeta) dbeta[c] = (float)S1;
+    if (s12) { s12[c] = (float)S1; s12[C + c] = (float)S2; }
+    if (cb) {
+      const float mean = coeff[c], istd = coeff[C + c], sc = coeff[2 * C + c];
+      const float m1 = training ? (float)(S1 / count) : 0.f, m2 = training ? (float)(S2 / count) : 0.f;
+      cb[c] = sc;
+      cb[C + c] = -sc * istd * m2;
+      cb[2 * C + c] = -sc * m1 + sc * istd * m2 * mean;
+    }
+  }
+}
+
+// in place: dh <- [bn1(c1) > 0] * scale * dh + Q * c1 + R
+__global__ void bn_relu_bwd_apply_kernel(float* __restrict__ dh, const float* __restrict__ c1,
+                                         const float* __restrict__ coeff, const float* __restrict__ cb, long n4,
+                                         int C) {
+  const int c4n = C >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const f32x4 d = *reinterpret_cast<const f32x4*>(dh + i * 4);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(c1 + i * 4);
+    const f32x4 scl = *reinterpret_cast<const f32x4*>(coeff + 2 * C + c);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(coeff + 3 * C + c);
+    const f32x4 k0 = *reinterpret_cast<const f32x4*>(cb + c);
+    const f32x4 k1 = *reinterpret_cast<const f32x4*>(cb + C + c);
+    const f32x4 k2 = *reinterpret_cast<const f32x4*>(cb + 2 * C + c);
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float g = fmaf(x[k], scl[k], sh[k]) > 0.f ? d[k] * k0[k] : 0.f;
+      o[k] = g + fmaf(k1[k], x[k], k2[k]);
+    }
+    *reinterpret_cast<f32x4*>(dh + i * 4) = o;
+  }
+}
+
+inline int ew_blocks(long n, int per_block = 256) {
+  long b = (n + per_block - 1) / per_block;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+MMSA_EXPORT int mmsa_stem_stats(const float* x, const float* w, const float* bias, float* partial, int B, int H, int W,
+                                void* stream) {
+  MMSA_REQUIRE(x && w && bias && partial && B > 0 && H > 0 && W > 0 && W <= 1024);
+  const size_t sh = (3 * (W + 2) + 8 * 2 * 32) * sizeof(float);
+  hipLaunchKernelGGL(stem_stats_kernel, dim3(B * H), dim3(256), sh, mmsa_stream(stream), x, w, bias, partial, H, W);
+  return mmsa_launch_status();
+}
+
+MMSA_EXPORT int mmsa_stem_apply_pool(const float* x, const float* w, const float* bias, const float* coeff, float* out,
+                                     int B, int H, int W, void* stream) {
+  MMSA_REQUIRE(x && w && bias && coeff && out && B > 0 && H >= 2 && H % 2 == 0 && W >= 2 && W <= 1024);
+  const size_t sh = 4 * (W + 2) * sizeof(float);
+  hipLaunchKernelGGL(stem_apply_pool_kernel, dim3(B * (H / 2)), dim3(256), sh, mmsa_stream(stream), x, w, bias, coeff,
+                     out, H, W);
+  return mmsa_launch_status();
+}
+
+// Stem backward.  scratch: at least B*(H/2)*(64 + 320) + 64 floats.  Writes dW[32*9], dbias[32], dgamma[32], dbeta[32].
+MMSA_EXPORT int mmsa_stem_bwd(const float* x, const float* w, const float* bias, const float* coeff, const float* dout,
+                              float* dW, float* dbias, float* dgamma, float* dbeta, float* scratch, int B, int H, int W,
+                              int training, void* stream) {
+  MMSA_REQUIRE(x && w && bias && coeff && dout && dW && dbias && dgamma && dbeta && scratch);
+  MMSA_REQUIRE(B > 0 && H >= 2 && H % 2 == 0 && W >= 2 && W <= 1024);
+  hipStream_t s = mmsa_stream(stream);
+  const int rows = B * (H / 2);
+  float* p1 = scratch;                    // [rows][2][32]
+  float* s12 = p1 + (long)rows * 64;      // [2][32]
+  float* p2 = s12 + 64;                   // [rows][320]
+  const size_t sh1 = (4 * (W + 2) + 8 * 2 * 32) * sizeof(float);
+  hipLaunchKernelGGL(stem_bwd_stats_kernel, dim3(rows), dim3(256), sh1, s, x, w, bias, coeff, dout, p1, H, W);
+  hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(1), dim3(256), 0, s, p1, rows, (double)B * H * W, coeff, dgamma, dbeta,
+                     s12, (float*)nullptr, 32, training);
+  const size_t sh2 = (4 * (W + 2) + 8 * 320) * sizeof(float);
+  const float inv_n = training ? 1.0f / ((float)B * H * W) : 0.f;
+  hipLaunchKernelGGL(stem_bwd_w_kernel, dim3(rows), dim3(256), sh2, s, x, w, bias, coeff, dout, s12, inv_n, p2, H, W);
+  hipLaunchKernelGGL(stem_bwd_w_finalize_kernel, dim3(5), dim3(256), 0, s, p2, rows, dW, dbias);
+  return mmsa_launch_status();
+}
+
+// BatchNorm coefficients from per-tile partial sums (training) or running statistics (eval).
+// bsum (optional) receives per-utterance channel sums of the raw input, [B][C].
+MMSA_EXPORT int mmsa_bn_finalize(const float* partial, int rows, int tiles_per_img, double count, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var, long long* nbt,
+                                 float momentum, float eps, int training, float* coeff, float* bsum, int C,
+                                 void* stream) {
+  MMSA_REQUIRE(gamma && beta && coeff && C > 0 && rows >= 0 && tiles_per_img > 0);
+  MMSA_REQUIRE(training ? (partial && count > 0) : (running_mean && running_var));
+  MMSA_REQUIRE(!bsum || (partial && rows % tiles_per_img == 0));
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(mmsa_cdiv(C, 64)), dim3(256), 0, mmsa_stream(stream), partial, rows,
+                     tiles_per_img, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, training, coeff,
+                     bsum, C);
+  return mmsa_launch_status();
+}
+
+MMSA_EXPORT int mmsa_bn_relu_apply(const float* x, const float* coeff, float* y, long npos, int C, void* stream) {
+  MMSA_REQUIRE(x && coeff && y && npos > 0 && C > 0 && C % 4 == 0);
+  const long n4 = npos * (C / 4);
+  hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, mmsa_stream(stream),
+                     reinterpret_cast<const f32x4*>(x), coeff, reinterpret_cast<f32x4*>(y), n4, C);
+  return mmsa_launch_status();
+}
+
+MMSA_EXPORT int mmsa_se_gate(const float* bsum, const float* coeff, const float* W1, const float* W2, int HW, float* gap,
+                             float* hid, float* gate, int B, int C, int Ch, void* stream) {
+  MMSA_REQUIRE(bsum && coeff && W1 && W2 && gap && hid && gate && B > 0 && C > 0 && C <= 256 && Ch > 0 && Ch <= 16);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), 0, mmsa_stream(stream), bsum, coeff, W1, W2, 1.0f / (float)HW,
+                     gap, hid, gate, C, Ch);
+  return mmsa_launch_status();
+}
+
+MMSA_EXPORT int mmsa_res_gate_relu_pool(const float* c2, const float* sc, const float* coeff2, const float* coeffs,
+                                        const float* gate, float* out, int B, int H, int W, int C, void* stream) {
+  MMSA_REQUIRE(c2 && sc && coeff2 && coeffs && gate && out && B > 0 && H >= 2 && W >= 2 && C % 4 == 0);
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(res_gate_relu_pool_kernel, dim3(ew_blocks(total)), dim3(256), 0, mmsa_stream(stream), c2, sc,
+                     coeff2, coeffs, gate, out, B, H, W, C);
+  return mmsa_launch_status();
+}
+
+MMSA_EXPORT int mmsa_gap_fwd(const float* x, float* out, int B, int P, int C, void* stream) {
+  MMSA_REQUIRE(x && out && B > 0 && P > 0 && C > 0);
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3(mmsa_cdiv((long)B * C, 256)), dim3(256), 0, mmsa_stream(stream), x, out, B, P,
+                     C);
+  return mmsa_launch_status();
+}
+
+MMSA_EXPORT int mmsa_gap_bwd(const float* dout, float* dx, int B, int P, int C, void* stream) {
+  MMSA_REQUIRE(dout && dx && B > 0 && P > 0 && C > 0);
+  hipLaunchKernelGGL(gap_bwd_kernel, dim3(ew_blocks((long)B * P * C)), dim3(256), 0, mmsa_stream(stream), dout, dx, B, P,
+                     C);
+  return mmsa_launch_status();
+}
+
+// Scratch floats needed by mmsa_resblock_bwd_ew for a given geometry.
+MMSA_EXPORT long mmsa_resblock_bwd_scratch_floats(int B, int H, int W, int C) {
+  if (B <= 0 || H < 2 || W < 2 || C < 64 || C > 256 || C % 64) return MMSA_ERR_ARG;
+  const int planes = 1024 / C, chunk = planes * 4;
+  const int P2 = (H / 2) * (W / 2);
+  const int nchunks = (P2 + chunk - 1) / chunk;
+  const int Ch = C / 16;
+  // partial[B][nchunks][3][C] + A[B][3][C] + du[B][C] + dhp[B][Ch] + dg[B][C] + tab[2*B*C + 4*C]
+  return (long)B * nchunks * 3 * C + (long)B * 3 * C + (long)B * C + (long)B * Ch + (long)B * C + 2L * B * C + 4L * C;
+}
+
+// Elementwise part of a residual block's backward (everything between the pooled output gradient and the
+// two convolution gradients):  dout[B,H/2,W/2,C] -> d_c2[B,H,W,C], d_sc[B,H,W,C] plus the gradients of
+// bn2 / shortcut-BN affine parameters and of the two squeeze-excite matrices.
+MMSA_EXPORT int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const float* sc, const float* coeff2,
+                                     const float* coeffs, const float* gate, const float* hid, const float* gap,
+                                     const float* bsum, const float* W1, const float* W2, float* d_c2, float* d_sc,
+                                     float* dgamma2, float* dbeta2, float* dgammas, float* dbetas, float* dW1,
+                                     float* dW2, float* scratch, int B, int H, int W, int C, int training,
+                                     void* stream) {
+  MMSA_REQUIRE(dout && c2 && sc && coeff2 && coeffs && gate && hid && gap && bsum && W1 && W2 && d_c2 && d_sc);
+  MMSA_REQUIRE(dgamma2 && dbeta2 && dgammas && dbetas && dW1 && dW2 && scratch);
+  MMSA_REQUIRE(B > 0 && H >= 2 && W >= 2 && C >= 64 && C <= 256 && C % 64 == 0);
+  hipStream_t s = mmsa_stream(stream);
+  const int planes = 1024 / C, chunk = planes * 4;
+  const int P2 = (H / 2) * (W / 2);
+  const int nchunks = (P2 + chunk - 1) / chunk;
+  const int Ch = C / 16;
+  float* partial = scratch;
+  float* A = partial + (long)B * nchunks * 3 * C;
+  float* du = A + (long)B * 3 * C;
+  float* dhp = du + (long)B * C;
+  float* dg = dhp + (long)B * Ch;
+  float* tab = dg + (long)B * C;
+  float* dz = d_sc;  // pass A writes dz where d_sc will end up; pass B converts it in place
+  if ((H & 1) || (W & 1)) {  // positions outside every pooling window receive no routed gradient
+    if (hipMemsetAsync(dz, 0, (size_t)B * H * W * C * sizeof(float), s) != hipSuccess) return MMSA_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(res_pool_bwd_kernel, dim3(B * nchunks), dim3(256), (size_t)planes * 3 * C * sizeof(float), s, dout,
+                     c2, sc, coeff2, coeffs, gate, dz, partial, H, W, C, chunk, nchunks);
+  hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), 0, s, partial, nchunks, coeff2, gate, hid, W1, W2, A, du, dhp,
+                     dg, C, Ch);
+  hipLaunchKernelGGL(rb_bwd_coeff_kernel, dim3(mmsa_cdiv(C, 64)), dim3(64), 0, s, A, gate, dg, bsum, coeff2, coeffs, B,
+                     C, (float)(H * W), dgamma2, dbeta2, dgammas, dbetas, tab, training);
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3(mmsa_cdiv(2L * C * Ch, 256)), dim3(256), 0, s, du, hid, dhp, gap, dW1, dW2,
+                     B, C, Ch);
+  const long total4 = (long)B * H * W * (C / 4);
+  hipLaunchKernelGGL(rb_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, s, dz, c2, sc, tab, d_c2, d_sc, B,
+                     (long)H * W, C);
+  return mmsa_launch_status();
+}
+
+MMSA_EXPORT long mmsa_bn_relu_bwd_scratch_floats(long npos, int C) {
+  if (npos <= 0 || C < 32 || C > 256 || C % 32) return MMSA_ERR_ARG;
+  const int pos_per_block = 256;
+  const long blocks = (npos + pos_per_block - 1) / pos_per_block;
+  return blocks * 2 * C + 3L * C;
+}
+
+// dh[npos][C] (gradient w.r.t. relu(bn(c1))) -> in place gradient w.r.t. c1; also dgamma/dbeta.
+MMSA_EXPORT int mmsa_bn_relu_bwd(float* dh, const float* c1, const float* coeff, float* dgamma, float* dbeta,
+                                 float* scratch, long npos, int C, int training, void* stream) {
+  MMSA_REQUIRE(dh && c1 && coeff && dgamma && dbeta && scratch && npos > 0);
+  MMSA_REQUIRE(C >= 32 && C <= 256 && C % 32 == 0);
+  hipStream_t s = mmsa_stream(stream);
+  const int pos_per_block = 256;
+  const int blocks = (int)((npos + pos_per_block - 1) / pos_per_block);
+  float* partial = scratch;
+  float* cb = scratch + (long)blocks * 2 * C;
+  const int planes = 1024 / C;
+  hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, dim3(blocks), dim3(256), (size_t)planes * 2 * C * sizeof(float), s, dh,
+                     c1, coeff, partial, npos, C, pos_per_block);
+  hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(mmsa_cdiv(C, 64)), dim3(256), 0, s, partial, blocks, (double)npos, coeff,
+                     dgamma, dbeta, (float*)nullptr, cb, C, training);
+  const long n4 = npos * (C / 4);
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dh, c1, coeff, cb, n4, C);
+  return mmsa_launch_status();
+}

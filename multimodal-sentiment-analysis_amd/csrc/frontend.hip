@@ -1,0 +1,190 @@
+// Log-mel front end: waveform [B, n] -> normalised log-mel map [B, 1, 64, 130].
+//
+// Replaces, for a batch of utterances at once, what the reference computes per utterance on the CPU in
+// `CNN implementation/preprocess.py:151-168` (pad/trim, MelSpectrogram, AmplitudeToDB, normalize, NaN scrub)
+// and `:111-123` (z-score with unbiased std, clamp to +-6).
+//
+// Kernel 1 (logmel_db): one workgroup per (utterance, group of FPB consecutive frames).  The group's
+//   (FPB+1)*512 reflect-padded samples are staged once in LDS (frames overlap by half), each frame is
+//   windowed, packed as a 512-point complex sequence, transformed with a radix-2 Stockham FFT in LDS,
+//   unpacked to the 513 one-sided power bins, multiplied by the (sparse, triangular) mel filterbank
+//   and converted to dB.  Output: dB map, coalesced over frames.
+// Kernel 2 (logmel_norm): one workgroup per utterance: max -> (max-80) floor -> mean / unbiased std
+//   (two-pass, double accumulators) -> (x-mean)/(std+1e-8) -> clamp -> NaN/Inf scrub, in place.
+#include "mmsa_common.h"
+
+namespace {
+
+constexpr int NFFT = 1024;
+constexpr int HOP = 512;
+constexpr int NBINS = 513;
+constexpr int NMEL = 64;
+constexpr int FPB = 5;  // frames per workgroup
+
+__global__ __launch_bounds__(256) void logmel_db_kernel(
+    const float* __restrict__ wave, long wave_stride, int n_valid, int n_target, int n_frames,
+    const float* __restrict__ window,   // [1024]
+    const float* __restrict__ tw512,    // [256][2]  cos, -sin of 2*pi*j/512
+    const float* __restrict__ tw1024,   // [513][2]  cos, -sin of 2*pi*k/1024
+    const float* __restrict__ melfb,    // [513][64]
+    const int* __restrict__ melrange,   // [64][2]   first bin, one-past-last bin with non-zero weight
+    float* __restrict__ out)            // [B][64][n_frames] dB
+{
+  __shared__ float seg[(FPB + 1) * HOP];
+  __shared__ float2 fa[512];
+  __shared__ float2 fb[512];
+  __shared__ float power[NBINS + 3];
+  __shared__ float dbv[NMEL][FPB + 1];
+
+  const int t = threadIdx.x;
+  const int b = blockIdx.y;
+  const int f0 = blockIdx.x * FPB;
+  const float* w = wave + (long)b * wave_stride;
+
+  // stage reflect-padded samples: padded index q = f0*512 + i  <->  sample n = q - 512
+  for (int i = t; i < (FPB + 1) * HOP; i += 256) {
+    int n = f0 * HOP + i - NFFT / 2;
+    if (n < 0) n = -n;
+    if (n >= n_target) n = 2 * (n_target - 1) - n;
+    float v = 0.f;
+    if (n >= 0 && n < n_valid) v = w[n];
+    seg[i] = v;
+  }
+  __syncthreads();
+
+  for (int fi = 0; fi < FPB; ++fi) {
+    if (f0 + fi >= n_frames) break;  // uniform
+    // window + pack even/odd samples into a 512-point complex sequence
+    {
+      const float* s = seg + fi * HOP;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int n = t + r * 256;
+        fa[n] = make_float2(s[2 * n] * window[2 * n], s[2 * n + 1] * window[2 * n + 1]);
+      }
+    }
+    float2* x = fa;
+    float2* y = fb;
+#pragma unroll 1
+    for (int p = 1; p < 512; p <<= 1) {
+      __syncthreads();
+      const int k = t & (p - 1);
+      const int j = ((t - k) << 1) + k;
+      const int ti = k * (256 / p);
+      const float c = tw512[2 * ti], sn = tw512[2 * ti + 1];
+      const float2 u0 = x[t];
+      const float2 v = x[t + 256];
+      const float2 u1 = make_float2(v.x * c - v.y * sn, v.x * sn + v.y * c);
+      y[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
+      y[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
+      float2* tmp = x; x = y; y = tmp;
+    }
+    __syncthreads();
+    // unpack the real-input spectrum: X[k] = (Z[k]+conj(Z[512-k]))/2 + W^k (Z[k]-conj(Z[512-k]))/(2i)
+    for (int k = t; k <= 512; k += 256) {
+      const float2 zk = x[k & 511];
+      const float2 zc = x[(512 - k) & 511];
+      const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);   // even part
+      const float dr = 0.5f * (zk.x - zc.x), di = 0.5f * (zk.y + zc.y);   // (Z - conj Z')/2
+      // odd part = (dr + i di) / i = di - i dr
+      const float orr = di, oi = -dr;
+      const float c = tw1024[2 * k], sn = tw1024[2 * k + 1];
+      const float xr = er + (orr * c - oi * sn);
+      const float xi = ei + (orr * sn + oi * c);
+      power[k] = xr * xr + xi * xi;
+    }
+    __syncthreads();
+    // mel: 4 lanes per filter, then dB
+    {
+      const int m = t >> 2, q = t & 3;
+      const int lo = melrange[2 * m], hi = melrange[2 * m + 1];
+      float acc = 0.f;
+      for (int f = lo + q; f < hi; f += 4) acc = fmaf(melfb[f * NMEL + m], power[f], acc);
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      if (q == 0) dbv[m][fi] = 10.0f * log10f(fmaxf(acc, 1e-10f));
+    }
+    // the next frame's first barrier orders power[] / fa[] reuse
+  }
+  __syncthreads();
+  for (int i = t; i < NMEL * FPB; i += 256) {
+    const int m = i / FPB, fi = i - m * FPB;
+    if (f0 + fi < n_frames) out[((long)b * NMEL + m) * n_frames + f0 + fi] = dbv[m][fi];
+  }
+}
+
+__global__ __launch_bounds__(256) void logmel_norm_kernel(float* __restrict__ io, int n_elem, float top_db) {
+  extern __shared__ float vals[];
+  __shared__ float redf[16];
+  __shared__ double redd[16];
+  const int t = threadIdx.x;
+  float* p = io + (long)blockIdx.x * n_elem;
+  float mx = -INFINITY;
+  for (int i = t; i < n_elem; i += 256) {
+    const float v = p[i];
+    vals[i] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = block_max(mx, redf);
+  const float floor_v = mx - top_db;
+  double s = 0.0;
+  for (int i = t; i < n_elem; i += 256) {
+    const float v = fmaxf(vals[i], floor_v);
+    vals[i] = v;
+    s += (double)v;
+  }
+  s = block_sum_d(s, redd);
+  const double mean = s / (double)n_elem;
+  double q = 0.0;
+  for (int i = t; i < n_elem; i += 256) {
+    const double d = (double)vals[i] - mean;
+    q += d * d;
+  }
+  q = block_sum_d(q, redd);
+  const float meanf = (float)mean;
+  const float stdf = (float)sqrt(q / (double)(n_elem - 1));
+  const float denom = stdf + 1e-8f;
+  for (int i = t; i < n_elem; i += 256) {
+    float v = (vals[i] - meanf) / denom;
+    v = fminf(fmaxf(v, -6.f), 6.f);
+    if (!(fabsf(v) <= 6.f)) v = 0.f;  // NaN scrub (Inf cannot survive the clamp)
+    p[i] = v;
+  }
+}
+
+}  // namespace
+
+// Host-side table builder (no GPU work): periodic Hann window and FFT twiddles, evaluated in double.
+MMSA_EXPORT int mmsa_logmel_tables_host(float* window /*[1024]*/, float* tw512 /*[512]*/, float* tw1024 /*[1026]*/) {
+  MMSA_REQUIRE(window && tw512 && tw1024);
+  const double pi = 3.14159265358979323846;
+  for (int n = 0; n < NFFT; ++n) window[n] = (float)(0.5 - 0.5 * cos(2.0 * pi * n / NFFT));
+  for (int j = 0; j < 256; ++j) {
+    tw512[2 * j] = (float)cos(2.0 * pi * j / 512.0);
+    tw512[2 * j + 1] = (float)(-sin(2.0 * pi * j / 512.0));
+  }
+  for (int k = 0; k <= 512; ++k) {
+    tw1024[2 * k] = (float)cos(2.0 * pi * k / 1024.0);
+    tw1024[2 * k + 1] = (float)(-sin(2.0 * pi * k / 1024.0));
+  }
+  return MMSA_OK;
+}
+
+// wave: [batch] rows of `n_valid` samples, row stride `wave_stride` floats.  Samples beyond n_valid are
+// zeros up to n_target (pad) and samples beyond n_target are ignored (trim).  out: [batch][1][64][n_frames].
+MMSA_EXPORT int mmsa_logmel_fwd(const float* wave, long wave_stride, int n_valid, int n_target, int batch,
+                                const float* window, const float* tw512, const float* tw1024, const float* melfb,
+                                const int* melrange, float top_db, float* out, void* stream) {
+  MMSA_REQUIRE(wave && window && tw512 && tw1024 && melfb && melrange && out);
+  MMSA_REQUIRE(batch > 0 && n_target >= NFFT && n_valid >= 0 && wave_stride >= 0);
+  if (n_valid > n_target) n_valid = n_target;
+  const int n_frames = 1 + n_target / HOP;
+  const int n_elem = NMEL * n_frames;
+  MMSA_REQUIRE((size_t)n_elem * sizeof(float) <= 60 * 1024);
+  dim3 grid(mmsa_cdiv(n_frames, FPB), batch);
+  hipLaunchKernelGGL(logmel_db_kernel, grid, dim3(256), 0, mmsa_stream(stream), wave, wave_stride, n_valid, n_target,
+                     n_frames, window, tw512, tw1024, melfb, melrange, out);
+  hipLaunchKernelGGL(logmel_norm_kernel, dim3(batch), dim3(256), n_elem * sizeof(float), mmsa_stream(stream), out,
+                     n_elem, top_db);
+  return mmsa_launch_status();
+}

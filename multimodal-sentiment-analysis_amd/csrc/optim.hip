@@ -1,0 +1,206 @@
+// Optimiser-side kernels over the flat parameter / gradient buffers:
+//  * per-tensor L2 norms (the reference adds 0.001 * sum_p ||p||_2 to the loss in 'both' mode,
+//    `CNN implementation/multimodal_model.py:456-462`) and the matching gradient 0.001 * p / ||p||,
+//  * global-norm gradient clipping (`torch.nn.utils.clip_grad_norm_(max_norm=1.0)`,
+//    `CNN implementation/multimodal_train.py:194`): coefficient min(1, max_norm / (total + 1e-6)),
+//  * AdamW with decoupled weight decay (`multimodal_train.py:481-485,195`; torch defaults).
+//
+// Tensors live back to back in one flat fp32 buffer (each start aligned to 256 floats, gaps hold zeros).
+// A host-built chunk table maps fixed-size chunks to tensors so that a workgroup never straddles two tensors:
+//   chunk_off[c] (start, floats), chunk_len[c], chunk_tensor[c]; tensor_first_chunk[t] .. tensor_first_chunk[t+1].
+// Reductions are two-stage with fixed summation order (no atomics).  All step-dependent scalars stay in device
+// memory (state[]), so a whole training step can be replayed from a captured HIP graph without host reads.
+#include "mmsa_common.h"
+
+namespace {
+
+// state[] layout (floats): 0 step count, 1 bias_correction1, 2 sqrt(bias_correction2), 3 clip coefficient,
+//                          4 total grad norm, 5 sum of parameter norms
+enum { ST_STEP = 0, ST_BC1 = 1, ST_BC2S = 2, ST_CLIP = 3, ST_GNORM = 4, ST_PNORM = 5 };
+
+// sum of squares per chunk of (a[i] + alpha * b[i] * inv_norm[tensor]) -- b optional
+__global__ __launch_bounds__(256) void chunk_sumsq_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ tnorm, float alpha,
+                                                          const long long* __restrict__ chunk_off,
+                                                          const int* __restrict__ chunk_len,
+                                                          const int* __restrict__ chunk_tensor,
+                                                          double* __restrict__ chunk_ss) {
+  __shared__ double red[16];
+  const int c = blockIdx.x;
+  const float* pa = a + chunk_off[c];
+  const int n = chunk_len[c];
+  float coef = 0.f;
+  const float* pb = nullptr;
+  if (b) {
+    const float nm = tnorm[chunk_tensor[c]];
+    coef = nm > 0.f ? alpha / nm : 0.f;
+    pb = b + chunk_off[c];
+  }
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float v = pa[i];
+    if (pb) v = fmaf(coef, pb[i], v);
+    s += (double)v * (double)v;
+  }
+  s = block_sum_d(s, red);
+  if (threadIdx.x == 0) chunk_ss[c] = s;
+}
+
+// per-tensor norms from chunk sums; out_sum = sum_t norm_t (fp32, registration order), out_l2 = sqrt(sum_t norm_t^2)
+__global__ void tensor_norms_kernel(const double* __restrict__ chunk_ss, const int* __restrict__ tensor_first_chunk,
+                                    int ntensors, float* __restrict__ tnorm, float* __restrict__ out_sum,
+                                    float* __restrict__ out_l2) {
+  __shared__ float nrm[1024];
+  for (int t = threadIdx.x; t < ntensors; t += blockDim.x) {
+    double s = 0.0;
+    for (int c = tensor_first_chunk[t]; c < tensor_first_chunk[t + 1]; ++c) s += chunk_ss[c];
+    const float v = (float)sqrt(s);
+    nrm[t] = v;
+    if (tnorm) tnorm[t] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float acc = 0.f;
+    double sq = 0.0;
+    for (int t = 0; t < ntensors; ++t) {
+      acc += nrm[t];
+      sq += (double)nrm[t] * (double)nrm[t];
+    }
+    if (out_sum) out_sum[0] = acc;
+    if (out_l2) out_l2[0] = (float)sqrt(sq);
+  }
+}
+
+__global__ void l2_grad_add_kernel(float* __restrict__ g, const float* __restrict__ p, const float* __restrict__ tnorm,
+                                   float lambda, const long long* __restrict__ chunk_off,
+                                   const int* __restrict__ chunk_len, const int* __restrict__ chunk_tensor) {
+  const int c = blockIdx.x;
+  const float nm = tnorm[chunk_tensor[c]];
+  if (!(nm > 0.f)) return;
+  const float coef = lambda / nm;
+  float* pg = g + chunk_off[c];
+  const float* pp = p + chunk_off[c];
+  const int n = chunk_len[c];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) pg[i] = fmaf(coef, pp[i], pg[i]);
+}
+
+__global__ void step_scalars_kernel(float* __restrict__ state, float beta1, float beta2, float max_norm, int do_clip) {
+  const float t = state[ST_STEP] + 1.f;
+  state[ST_STEP] = t;
+  state[ST_BC1] = 1.f - powf(beta1, t);
+  state[ST_BC2S] = sqrtf(1.f - powf(beta2, t));
+  float coef = 1.f;
+  if (do_clip) coef = fminf(max_norm / (state[ST_GNORM] + 1e-6f), 1.f);
+  state[ST_CLIP] = coef;
+}
+
+__global__ void scale_inplace_by_state_kernel(float* __restrict__ g, long n, const float* __restrict__ state, int idx) {
+  const float coef = state[idx];
+  if (coef == 1.f) return;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) g[i] *= coef;
+}
+
+// p, m, v updated in place from g * clip (+ optional L2-term gradient lambda * p / ||p||, computed on the fly)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long n4,
+                                                    const float* __restrict__ state, float lr, float beta1, float beta2,
+                                                    float eps, float wd) {
+  const float clip = state[ST_CLIP], bc1 = state[ST_BC1], bc2s = state[ST_BC2S];
+  const float step_size = lr / bc1;
+  const float decay = 1.f - lr * wd;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = gg[k] * clip;
+      pp[k] *= decay;
+      mm[k] = mm[k] + (1.f - beta1) * (gr - mm[k]);
+      vv[k] = vv[k] * beta2 + (1.f - beta2) * gr * gr;
+      const float denom = sqrtf(vv[k]) / bc2s + eps;
+      pp[k] -= step_size * (mm[k] / denom);
+    }
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    reinterpret_cast<f32x4*>(m)[i] = mm;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+  }
+}
+
+__global__ void add_scaled_scalar_kernel(float* __restrict__ dst, const float* __restrict__ a,
+                                         const float* __restrict__ b, float alpha) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) dst[0] = a[0] + alpha * b[0];
+}
+
+}  // namespace
+
+// Per-tensor L2 norms of the flat buffer `p` -> tnorm[ntensors]; sum of norms -> state[5] (and *sum_out if given).
+MMSA_EXPORT int mmsa_param_norms(const float* p, const long long* chunk_off, const int* chunk_len,
+                                 const int* chunk_tensor, int nchunks, const int* tensor_first_chunk, int ntensors,
+                                 double* chunk_ss, float* tnorm, float* sum_out, void* stream) {
+  MMSA_REQUIRE(p && chunk_off && chunk_len && chunk_tensor && tensor_first_chunk && chunk_ss && tnorm);
+  MMSA_REQUIRE(nchunks > 0 && ntensors > 0 && ntensors <= 1024);
+  hipStream_t s = mmsa_stream(stream);
+  hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, p, (const float*)nullptr,
+                     (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss);
+  hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(256), 0, s, chunk_ss, tensor_first_chunk, ntensors, tnorm,
+                     sum_out, (float*)nullptr);
+  return mmsa_launch_status();
+}
+
+// g += lambda * p / ||p|| per tensor (tensors with zero norm are left alone, as torch.norm's gradient is 0 there)
+MMSA_EXPORT int mmsa_l2_grad_add(float* g, const float* p, const float* tnorm, float lambda, const long long* chunk_off,
+                                 const int* chunk_len, const int* chunk_tensor, int nchunks, void* stream) {
+  MMSA_REQUIRE(g && p && tnorm && chunk_off && chunk_len && chunk_tensor && nchunks > 0);
+  hipLaunchKernelGGL(l2_grad_add_kernel, dim3(nchunks), dim3(256), 0, mmsa_stream(stream), g, p, tnorm, lambda, chunk_off,
+                     chunk_len, chunk_tensor);
+  return mmsa_launch_status();
+}
+
+// total gradient norm = || (||g_1||, ..., ||g_T||) ||_2  -> state[4]
+MMSA_EXPORT int mmsa_grad_norm(const float* g, const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
+                               int nchunks, const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* state,
+                               void* stream) {
+  MMSA_REQUIRE(g && chunk_off && chunk_len && chunk_tensor && tensor_first_chunk && chunk_ss && state);
+  MMSA_REQUIRE(nchunks > 0 && ntensors > 0 && ntensors <= 1024);
+  hipStream_t s = mmsa_stream(stream);
+  hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, g, (const float*)nullptr,
+                     (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss);
+  hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(256), 0, s, chunk_ss, tensor_first_chunk, ntensors,
+                     (float*)nullptr, (float*)nullptr, state + ST_GNORM);
+  return mmsa_launch_status();
+}
+
+// One AdamW step over the flat buffers (n floats, n % 4 == 0).  state[0] (step count) advances by one; the clip
+// coefficient is derived from state[4] (call mmsa_grad_norm first) when do_clip != 0.
+MMSA_EXPORT int mmsa_adamw_step(float* p, const float* g, float* m, float* v, long n, float* state, float lr,
+                                float beta1, float beta2, float eps, float weight_decay, float max_norm, int do_clip,
+                                void* stream) {
+  MMSA_REQUIRE(p && g && m && v && state && n > 0 && n % 4 == 0);
+  hipStream_t s = mmsa_stream(stream);
+  hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, s, state, beta1, beta2, max_norm, do_clip);
+  const long n4 = n / 4;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n4, state, lr, beta1, beta2, eps,
+                     weight_decay);
+  return mmsa_launch_status();
+}
+
+// g *= state[idx]  (used to apply the clip coefficient in place for callers that run their own optimiser)
+MMSA_EXPORT int mmsa_scale_by_state(float* g, long n, const float* state, int idx, void* stream) {
+  MMSA_REQUIRE(g && state && n > 0 && idx >= 0 && idx < 8);
+  long blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_inplace_by_state_kernel, dim3((unsigned)blocks), dim3(256), 0, mmsa_stream(stream), g, n, state,
+                     idx);
+  return mmsa_launch_status();
+}
+
+// dst[0] = a[0] + alpha * b[0]   (loss = cross-entropy + 0.001 * sum of parameter norms, on device)
+MMSA_EXPORT int mmsa_scalar_axpy(float* dst, const float* a, const float* b, float alpha, void* stream) {
+  MMSA_REQUIRE(dst && a && b);
+  hipLaunchKernelGGL(add_scaled_scalar_kernel, dim3(1), dim3(64), 0, mmsa_stream(stream), dst, a, b, alpha);
+  return mmsa_launch_status();
+}

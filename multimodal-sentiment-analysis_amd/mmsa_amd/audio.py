@@ -1,0 +1,145 @@
+"""Audio branch: launch sequences for forward and backward over the HIP kernels.
+
+Computes what `CNN implementation/multimodal_model.py:118-129` (AudioModel.forward) and `:64-70`
+(ResidualBlock.forward) compute, on channels-last activations.  Nothing here does arithmetic: it sizes
+buffers and orders kernel launches.  BatchNorm statistics ride on the convolution epilogues, the
+conv->BN->ReLU->pool stem never materialises its full-resolution output, and SE / residual add / ReLU /
+max-pool are one kernel.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from .workspace import Grads, Workspace
+
+
+def _bn_args(bn):
+    return bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked
+
+
+def _pack(ws: Workspace, name: str, w: torch.Tensor, need_dgrad: bool):
+    f = ws.buf(name + ".wf", w.numel())
+    d = ws.buf(name + ".wd", w.numel()) if need_dgrad else None
+    ops.pack_weights(w, f, d)
+    return f, d
+
+
+def _conv_bn(ws, name, X, wf, bn, B, H, W, Cin, Cout, taps, training, want_bsum):
+    """conv (+ statistics epilogue when needed) followed by the BatchNorm coefficient kernel."""
+    Y = ws.buf(name + ".y", (B, H, W, Cout))
+    coeff = ws.buf(name + ".coeff", 4 * Cout)
+    need_stats = training or want_bsum
+    rows, tiles = ops.conv_stats_rows(B, H, W, Cout)
+    stats = ws.buf(name + ".stats", rows * 2 * Cout) if need_stats else None
+    ops.conv_fwd(X, wf, Y, stats, B, H, W, Cin, Cout, taps)
+    bsum = ws.buf(name + ".bsum", (B, Cout)) if want_bsum else None
+    g, b, rm, rv, nbt = _bn_args(bn)
+    ops.bn_finalize(stats, rows, tiles, B * H * W, g, b, rm, rv, nbt, training, coeff, bsum, Cout)
+    return Y, coeff, bsum
+
+
+def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: Workspace):
+    """One ResidualBlock + the 2x2 max-pool that follows it.  a_in: [B,H,W,Cin] -> [B,H/2,W/2,Cout]."""
+    s = SimpleNamespace(B=B, H=H, W=W, Cin=Cin, Cout=Cout, a_in=a_in, name=name)
+    s.w1f, s.w1d = _pack(ws, name + ".c1", blk.conv1.weight, need_grad)
+    s.w2f, s.w2d = _pack(ws, name + ".c2", blk.conv2.weight, need_grad)
+    s.wsf, s.wsd = _pack(ws, name + ".sc", blk.shortcut[0].weight, need_grad)
+    s.c1, s.coeff1, _ = _conv_bn(ws, name + ".c1", a_in, s.w1f, blk.bn1, B, H, W, Cin, Cout, ops.TAPS3X3, training,
+                                 False)
+    s.h1 = ws.buf(name + ".h1", (B, H, W, Cout))
+    ops.bn_relu_apply(s.c1, s.coeff1, s.h1, B * H * W, Cout)
+    s.c2, s.coeff2, s.bsum2 = _conv_bn(ws, name + ".c2", s.h1, s.w2f, blk.bn2, B, H, W, Cout, Cout, ops.TAPS3X3,
+                                       training, True)
+    s.sc, s.coeffs, _ = _conv_bn(ws, name + ".sc", a_in, s.wsf, blk.shortcut[1], B, H, W, Cin, Cout, ops.TAPS1X1,
+                                 training, False)
+    W1, W2 = blk.se.fc[0].weight, blk.se.fc[2].weight
+    Ch = W1.shape[0]
+    s.gap = ws.buf(name + ".gap", (B, Cout))
+    s.hid = ws.buf(name + ".hid", (B, Ch))
+    s.gate = ws.buf(name + ".gate", (B, Cout))
+    ops.se_gate(s.bsum2, s.coeff2, W1, W2, H * W, s.gap, s.hid, s.gate, B, Cout)
+    s.out = ws.buf(name + ".out", (B, H // 2, W // 2, Cout))
+    ops.res_gate_relu_pool(s.c2, s.sc, s.coeff2, s.coeffs, s.gate, s.out, B, H, W, Cout)
+    return s
+
+
+def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx: bool):
+    """d_out: [B,H/2,W/2,Cout] -> gradient w.r.t. the block input [B,H,W,Cin] (or None)."""
+    B, H, W, Cin, Cout, name = s.B, s.H, s.W, s.Cin, s.Cout, s.name
+    W1, W2 = blk.se.fc[0].weight, blk.se.fc[2].weight
+    d_c2 = ws.buf(name + ".d_c2", (B, H, W, Cout))
+    d_sc = ws.buf(name + ".d_sc", (B, H, W, Cout))
+    scratch = ws.buf(name + ".bwd_scratch", ops.resblock_bwd_scratch(B, H, W, Cout))
+    bn2, bns = blk.bn2, blk.shortcut[1]
+    ops.resblock_bwd_ew(d_out, s.c2, s.sc, s.coeff2, s.coeffs, s.gate, s.hid, s.gap, s.bsum2, W1, W2, d_c2, d_sc,
+                        grads.of(bn2.weight), grads.of(bn2.bias), grads.of(bns.weight), grads.of(bns.bias),
+                        grads.of(W1), grads.of(W2), scratch, B, H, W, Cout, training)
+    wsz = max(ops.conv_wgrad_workspace(B, H, W, Cout, Cout, 9), ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 9),
+              ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 1))
+    wg = ws.buf(name + ".wgrad_ws", wsz)
+    ops.conv_wgrad(s.h1, d_c2, grads.of(blk.conv2.weight), wg, B, H, W, Cout, Cout, ops.TAPS3X3)
+    d_h1 = ws.buf(name + ".d_h1", (B, H, W, Cout))
+    ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
+    sc2 = ws.buf(name + ".bnrelu_scratch", ops.bn_relu_bwd_scratch(B * H * W, Cout))
+    ops.bn_relu_bwd(d_h1, s.c1, s.coeff1, grads.of(blk.bn1.weight), grads.of(blk.bn1.bias), sc2, B * H * W, Cout,
+                    training)
+    d_c1 = d_h1
+    ops.conv_wgrad(s.a_in, d_c1, grads.of(blk.conv1.weight), wg, B, H, W, Cin, Cout, ops.TAPS3X3)
+    ops.conv_wgrad(s.a_in, d_sc, grads.of(blk.shortcut[0].weight), wg, B, H, W, Cin, Cout, ops.TAPS1X1)
+    if not need_dx:
+        return None
+    d_in = ws.buf(name + ".d_in", (B, H, W, Cin))
+    ops.conv_fwd(d_c1, s.w1d, d_in, None, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
+    ops.conv_fwd(d_sc, s.wsd, d_in, None, B, H, W, Cout, Cin, ops.TAPS1X1, negate=True, accumulate=True)
+    return d_in
+
+
+def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Workspace):
+    """x: [B,1,H,W] (or [B,H,W]) float32 on the GPU -> (features [B,256], saved state)."""
+    if x.dim() == 4:
+        if x.shape[1] != 1:
+            raise ValueError("audio input must have one channel")
+        B, _, H, W = x.shape
+    elif x.dim() == 3:
+        B, H, W = x.shape
+    else:
+        raise ValueError("audio input must be [B,1,H,W]")
+    if H % 16 or W < 16:
+        raise ValueError("spectrogram height must be a multiple of 16 and width at least 16")
+    x = x.contiguous()
+    st = SimpleNamespace(B=B, H=H, W=W, x=x, blocks=[])
+    conv0, bn0 = m.conv1[0], m.conv1[1]
+    g, b, rm, rv, nbt = _bn_args(bn0)
+    st.coeff0 = ws.buf("stem.coeff", 128)
+    partial = None
+    if training:
+        partial = ws.buf("stem.partial", B * H * 64)
+        ops.stem_stats(x, conv0.weight, conv0.bias, partial, B, H, W)
+    ops.bn_finalize(partial, B * H, H, B * H * W, g, b, rm, rv, nbt, training, st.coeff0, None, 32)
+    a = ws.buf("stem.out", (B, H // 2, W // 2, 32))
+    ops.stem_apply_pool(x, conv0.weight, conv0.bias, st.coeff0, a, B, H, W)
+    h, w, cin = H // 2, W // 2, 32
+    for i, blk in enumerate((m.res_block1, m.res_block2, m.res_block3)):
+        cout = blk.conv1.weight.shape[0]
+        s = block_forward(blk, f"rb{i + 1}", a, B, h, w, cin, cout, training, need_grad, ws)
+        st.blocks.append(s)
+        a, h, w, cin = s.out, h // 2, w // 2, cout
+    st.P, st.C = h * w, cin
+    feat = ws.buf("audio.feat", (B, cin))
+    ops.gap_fwd(a, feat, B, st.P, cin)
+    return feat, st
+
+
+def audio_backward(m, st, dfeat: torch.Tensor, training: bool, grads: Grads, ws: Workspace):
+    B = st.B
+    d = ws.buf("audio.d_last", (B, st.P, st.C))
+    ops.gap_bwd(dfeat.contiguous(), d, B, st.P, st.C)
+    for blk, s in zip((m.res_block3, m.res_block2, m.res_block1), reversed(st.blocks)):
+        d = block_backward(blk, s, d, training, grads, ws, need_dx=True)
+    conv0, bn0 = m.conv1[0], m.conv1[1]
+    scratch = ws.buf("stem.bwd_scratch", ops.stem_bwd_scratch(B, st.H))
+    ops.stem_bwd(st.x, conv0.weight, conv0.bias, st.coeff0, d, grads.of(conv0.weight), grads.of(conv0.bias),
+                 grads.of(bn0.weight), grads.of(bn0.bias), scratch, B, st.H, st.W, training)

@@ -1,0 +1,211 @@
+"""Log-mel front end on the GPU, behind the reference's `AudioTransform` interface.
+
+`CNN implementation/preprocess.py:45-174` runs per utterance on CPU worker processes.  Here the mel stage
+(`:151-168`: pad/trim, power spectrogram, mel filterbank, dB with top_db 80, z-score, clamp, NaN scrub) is one
+batched HIP call: :class:`LogMelFrontEnd` maps ``[B, n]`` waveforms to ``[B, 1, 64, 130]``.
+:class:`AudioTransform` keeps the reference's per-utterance call signature on top of it.
+
+Not covered here (they sit before the kernel boundary and depend on packages absent from this image):
+resampling from other sample rates and spectral-gating noise reduction (`preprocess.py:131-148`).
+"""
+from __future__ import annotations
+
+import math
+import os
+import random
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+SAMPLE_RATE = 22050
+N_FFT = 1024
+HOP_LENGTH = 512
+N_MELS = 64
+MAX_AUDIO_LENGTH = 3
+TARGET_LENGTH = SAMPLE_RATE * MAX_AUDIO_LENGTH
+N_FRAMES = 1 + TARGET_LENGTH // HOP_LENGTH
+TOP_DB = 80.0
+
+
+def set_seed(seed=42):
+    """preprocess.py:26-33 (the cudnn flags have no HIP-kernel counterpart: these kernels are deterministic)."""
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+
+
+def htk_mel_filterbank() -> torch.Tensor:
+    """[513, 64] fp32 triangular HTK filterbank, f_min 0, f_max sr//2, no normalisation -- the parameters the
+    reference passes to MelSpectrogram (preprocess.py:47-52), evaluated in fp32 in the same order of operations."""
+    n_freqs = N_FFT // 2 + 1
+    freqs = torch.linspace(0, SAMPLE_RATE // 2, n_freqs)
+    mel_lo = 2595.0 * math.log10(1.0)
+    mel_hi = 2595.0 * math.log10(1.0 + float(SAMPLE_RATE // 2) / 700.0)
+    pts = 700.0 * (10.0 ** (torch.linspace(mel_lo, mel_hi, N_MELS + 2) / 2595.0) - 1.0)
+    width = pts[1:] - pts[:-1]
+    slope = pts.unsqueeze(0) - freqs.unsqueeze(1)
+    rising = (-1.0 * slope[:, :-2]) / width[:-1]
+    falling = slope[:, 2:] / width[1:]
+    return torch.clamp(torch.minimum(rising, falling), min=0.0).contiguous()
+
+
+def _tables(device):
+    import ctypes
+    win = np.zeros(N_FFT, np.float32)
+    t5 = np.zeros(512, np.float32)
+    t10 = np.zeros(1026, np.float32)
+    _lib.call("mmsa_logmel_tables_host", win.ctypes.data_as(ctypes.c_void_p), t5.ctypes.data_as(ctypes.c_void_p),
+              t10.ctypes.data_as(ctypes.c_void_p))
+    fb = htk_mel_filterbank()
+    rng = np.zeros((N_MELS, 2), np.int32)
+    nz = fb.numpy() > 0
+    for m in range(N_MELS):
+        idx = np.nonzero(nz[:, m])[0]
+        rng[m] = (idx[0], idx[-1] + 1) if idx.size else (0, 0)
+    return {
+        "window": torch.from_numpy(win).to(device), "tw512": torch.from_numpy(t5).to(device),
+        "tw1024": torch.from_numpy(t10).to(device), "melfb": fb.to(device),
+        "melrange": torch.from_numpy(rng).to(device),
+    }
+
+
+class LogMelFrontEnd:
+    """Batched mel stage.  ``fe(wave[B, n]) -> [B, 1, 64, 130]`` on ``device``; rows shorter than 66 150 samples are
+    zero-padded, longer ones trimmed (preprocess.py:151-156)."""
+
+    def __init__(self, device="cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MmsaError("LogMelFrontEnd runs on an MI355X only; there is no CPU path")
+        _lib.load()
+        self.tables = _tables(self.device)
+
+    def __call__(self, wave: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        if wave.dim() == 1:
+            wave = wave.unsqueeze(0)
+        if wave.dim() != 2:
+            raise ValueError("wave must be [B, n_samples]")
+        wave = wave.to(device=self.device, dtype=torch.float32)
+        if wave.stride(1) != 1:
+            wave = wave.contiguous()
+        if out is None:
+            out = torch.empty((wave.shape[0], 1, N_MELS, N_FRAMES), dtype=torch.float32, device=self.device)
+        return ops.logmel(wave, self.tables, out, TARGET_LENGTH, TOP_DB)
+
+
+class AudioTransform:
+    """Per-utterance interface of the reference (``transform(audio[C, T], sr) -> [1, 64, 130]`` CPU tensor).
+
+    The spectrogram is computed by the HIP front end, so call it from the process that owns the GPU
+    (``DataLoader(num_workers=0)``), or use ``waveform_only=True`` in worker processes -- they then return the
+    prepared ``[1, 66150]`` waveform and the training process runs :class:`LogMelFrontEnd` on whole batches.
+    Waveform augmentations follow preprocess.py:56-90 with the same ``random`` draw order.
+    """
+
+    def __init__(self, augment=False, device="cuda", waveform_only=False):
+        self.augment = augment
+        self.device = device
+        self.waveform_only = waveform_only
+        self._fe = None
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["_fe"] = None            # device tables are rebuilt lazily in the receiving process
+        return d
+
+    # -- augmentations (host side, training only) ------------------------------------------------
+    def time_shift(self, audio, shift_limit=0.1):
+        if random.random() < 0.5:
+            return audio
+        shift = int(random.random() * shift_limit * audio.shape[1])
+        right = random.random() > 0.5
+        out = torch.zeros_like(audio)
+        n = audio.shape[1]
+        if shift == 0:
+            # the reference's slices (`audio[:, :-0]`) are empty for a zero shift: the result is all zeros
+            return out
+        if right:
+            out[:, shift:] = audio[:, :n - shift]
+        else:
+            out[:, :n - shift] = audio[:, shift:]
+        return out
+
+    def add_noise(self, audio, noise_factor=0.005):
+        if random.random() < 0.5:
+            return audio
+        return audio + torch.randn_like(audio) * noise_factor
+
+    def pitch_shift(self, audio, sr):
+        if random.random() < 0.5:
+            return audio
+        factor = random.uniform(0.9, 1.1)
+        idx = torch.arange(0, audio.shape[1], factor).clamp(0, audio.shape[1] - 1).long()
+        return audio[:, idx]
+
+    def spectral_mask(self, spec, max_mask_freq=8, max_mask_time=8):
+        if random.random() < 0.5:
+            return spec
+        if random.random() < 0.5:
+            size = random.randint(1, max_mask_freq)
+            start = random.randint(0, spec.shape[1] - size)
+            spec[:, start:start + size, :] = 0
+        if random.random() < 0.5:
+            size = random.randint(1, max_mask_time)
+            start = random.randint(0, spec.shape[2] - size)
+            spec[:, :, start:start + size] = 0
+        return spec
+
+    def prepare_waveform(self, audio: torch.Tensor, sr: int = SAMPLE_RATE) -> torch.Tensor:
+        """Everything before the mel stage that this build covers: mono mix, augmentation, pad/trim."""
+        if audio.dim() == 1:
+            audio = audio.unsqueeze(0)
+        if audio.shape[0] > 1:
+            audio = audio.mean(dim=0, keepdim=True)
+        if sr != SAMPLE_RATE:
+            raise NotImplementedError(
+                f"resampling {sr} Hz -> {SAMPLE_RATE} Hz is outside this build's kernel boundary "
+                "(the reference uses torchaudio.transforms.Resample, absent here); resample upstream")
+        if self.augment:
+            audio = self.time_shift(audio)
+            audio = self.add_noise(audio)
+            audio = self.pitch_shift(audio, SAMPLE_RATE)
+        n = audio.shape[1]
+        if n < TARGET_LENGTH:
+            audio = torch.nn.functional.pad(audio, (0, TARGET_LENGTH - n))
+        elif n > TARGET_LENGTH:
+            audio = audio[:, :TARGET_LENGTH]
+        return audio
+
+    def __call__(self, audio, sr=SAMPLE_RATE):
+        wave = self.prepare_waveform(audio, sr)
+        if self.waveform_only:
+            return wave
+        if self.augment:
+            # the reference masks the dB map BEFORE normalising (preprocess.py:162-165); the fused kernel
+            # normalises in the same launch, so augmentation takes the unfused route below
+            raise NotImplementedError("spectral masking needs the un-normalised dB map: use waveform_only=True "
+                                      "and the batched front end for augmented training data")
+        if self._fe is None:
+            self._fe = LogMelFrontEnd(self.device)
+        return self._fe(wave)[0].cpu()
+
+
+def calculate_class_weights(csv_path):
+    """'balanced' class weights n / (k * count_c) over the CSV's Sentiment column (preprocess.py:259-292);
+    falls back to ones if the file cannot be read, as the reference does."""
+    label_map = {"negative": 0, "-1": 0, "-1.0": 0, "neutral": 1, "0": 1, "0.0": 1, "positive": 2, "1": 2, "1.0": 2}
+    try:
+        with open(csv_path) as f:
+            header = f.readline().rstrip("\n").split(";")
+            col = header.index("Sentiment")
+            y = [label_map.get(line.rstrip("\n").split(";")[col].strip(), 1) for line in f if line.strip()]
+        classes, counts = np.unique(np.asarray(y), return_counts=True)
+        w = len(y) / (len(classes) * counts.astype(np.float64))
+        return torch.tensor(w, dtype=torch.float)
+    except Exception:
+        return torch.tensor([1.0, 1.0, 1.0], dtype=torch.float)

@@ -1,0 +1,470 @@
+"""Drop-in modules for `CNN implementation/multimodal_model.py`.
+
+Same class names, constructor signatures, attribute names and ``state_dict`` keys as the reference, so
+checkpoints written by its training driver (`multimodal_train.py:338-358`) load with ``strict=True`` and a
+seeded construction consumes torch's global RNG in the same order (identical initial weights).  The stock
+``nn.Conv2d`` / ``nn.Linear`` / ... leaves are used purely as parameter containers: their ``forward`` is never
+called.  All arithmetic runs in the HIP library through :mod:`mmsa_amd.audio`, :mod:`mmsa_amd.text` and
+:mod:`mmsa_amd.head`; there is no CPU or ATen fallback -- a model left on the CPU raises on ``forward``.
+
+Training support comes in two forms:
+* ``loss.backward()`` works (one ``autograd.Function`` spans the whole model; its backward runs the HIP backward
+  kernels), so the reference's training loop runs unchanged with ``torch.optim.AdamW`` + ``clip_grad_norm_``;
+* :class:`mmsa_amd.trainer.TrainStep` runs forward + backward + clip + AdamW without autograd, over flat
+  parameter / gradient buffers, and can replay the whole step from a captured HIP graph.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib, audio as audio_engine, head as head_engine, ops, text as text_engine
+from .arena import ParamArena
+from .workspace import Grads, Workspace
+
+L2_LAMBDA = 0.001
+INFER_CHUNK = 256
+
+
+def _stack(spec) -> nn.Sequential:
+    """Build an ``nn.Sequential`` from a compact spec; positions matter (they are the state_dict indices)."""
+    makers = {
+        "lin": lambda a, b: nn.Linear(a, b),
+        "lin_nobias": lambda a, b: nn.Linear(a, b, bias=False),
+        "ln": lambda n: nn.LayerNorm(n),
+        "bn1": lambda n: nn.BatchNorm1d(n),
+        "bn2": lambda n: nn.BatchNorm2d(n),
+        "relu": lambda: nn.ReLU(),
+        "drop": lambda p: nn.Dropout(p),
+        "flat": lambda: nn.Flatten(),
+        "sigmoid": lambda: nn.Sigmoid(),
+        "softmax": lambda: nn.Softmax(dim=1),
+        "pool": lambda: nn.MaxPool2d(2, 2),
+        "conv3": lambda a, b, bias: nn.Conv2d(a, b, 3, 1, 1, bias=bias),
+        "conv1": lambda a, b: nn.Conv2d(a, b, 1, 1, bias=False),
+    }
+    return nn.Sequential(*[makers[s[0]](*s[1:]) for s in spec])
+
+
+def _no_standalone(name):
+    raise NotImplementedError(
+        f"{name}.forward is fused into its parent's HIP launch sequence and has no stand-alone kernel path; "
+        "call AudioModel / TextModel / MultimodalSentimentModel instead")
+
+
+class Attention(nn.Module):
+    """Present for import compatibility (multimodal_model.py:5-24); the reference never instantiates it."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.query, self.key, self.value = nn.Linear(dim, dim), nn.Linear(dim, dim), nn.Linear(dim, dim)
+        self.scale = dim ** 0.5
+
+    def forward(self, x):
+        _no_standalone("Attention")
+
+
+class SEBlock(nn.Module):
+    """Parameters of multimodal_model.py:27-36; evaluated inside the residual-block kernels."""
+
+    def __init__(self, channels, reduction=16):
+        super().__init__()
+        self.fc = _stack([("lin_nobias", channels, channels // reduction), ("relu",),
+                          ("lin_nobias", channels // reduction, channels), ("sigmoid",)])
+
+    def forward(self, x):
+        _no_standalone("SEBlock")
+
+
+class ResidualBlock(nn.Module):
+    """Parameters of multimodal_model.py:46-62 (stride 1 with a projection shortcut is what the model uses)."""
+
+    def __init__(self, in_channels, out_channels, stride=1):
+        super().__init__()
+        if stride != 1 or in_channels == out_channels:
+            raise NotImplementedError("the HIP path covers the stride-1 projection-shortcut blocks the model uses")
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(out_channels)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(out_channels)
+        self.shortcut = _stack([("conv1", in_channels, out_channels), ("bn2", out_channels)])
+        self.se = SEBlock(out_channels)
+
+    def forward(self, x):
+        _no_standalone("ResidualBlock")
+
+
+def _require_gpu(module: nn.Module, what: str):
+    p = next(module.parameters())
+    if not p.is_cuda:
+        raise _lib.MmsaError(f"{what}: parameters are on {p.device}; the HIP kernels run on an MI355X only "
+                             "(move the module with .to('cuda')); there is no CPU fallback")
+    _lib.load()
+    return p.device
+
+
+def _needs_grad(module: nn.Module) -> bool:
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
+
+class _BranchFn(torch.autograd.Function):
+    """Autograd bridge for a single branch used on its own (AudioModel(x) / TextModel(ids))."""
+
+    @staticmethod
+    def forward(ctx, module, inp, *params):
+        ws = Workspace(inp.device, persistent=False)
+        if isinstance(module, AudioModel):
+            feat, st = audio_engine.audio_forward(module, inp, module.training, True, ws)
+        else:
+            feat, st = text_engine.text_forward(module, inp, True, ws)
+        ctx.module, ctx.st, ctx.ws, ctx.training = module, st, ws, module.training
+        ctx.set_materialize_grads(False)
+        return feat.clone()
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        m = ctx.module
+        plist = list(m.parameters())
+        if dfeat is None:
+            return (None, None) + tuple(None for _ in plist)
+        grads = Grads()
+        if isinstance(m, AudioModel):
+            audio_engine.audio_backward(m, ctx.st, dfeat, ctx.training, grads, ctx.ws)
+        else:
+            text_engine.text_backward(m, ctx.st, dfeat, grads)
+        return (None, None) + tuple(grads.get(p) for p in plist)
+
+
+class AudioModel(nn.Module):
+    def __init__(self, num_classes=3, dropout_rate=0.5):
+        super().__init__()
+        self.conv1 = _stack([("conv3", 1, 32, True), ("bn2", 32), ("relu",), ("pool",)])
+        self.res_block1 = ResidualBlock(32, 64)
+        self.pool1 = nn.MaxPool2d(2, 2)
+        self.res_block2 = ResidualBlock(64, 128)
+        self.pool2 = nn.MaxPool2d(2, 2)
+        self.res_block3 = ResidualBlock(128, 256)
+        self.pool3 = nn.MaxPool2d(2, 2)
+        self.gap = nn.AdaptiveAvgPool2d(1)
+        self.feature_dim = 256
+        self._initialize_weights()
+
+    def _initialize_weights(self):
+        # multimodal_model.py:104-116: He-normal (fan_out) convs, unit BatchNorm, N(0, 0.01) SE matrices
+        for mod in self.modules():
+            if isinstance(mod, nn.Conv2d):
+                nn.init.kaiming_normal_(mod.weight, mode="fan_out", nonlinearity="relu")
+                if mod.bias is not None:
+                    nn.init.constant_(mod.bias, 0)
+            elif isinstance(mod, nn.BatchNorm2d):
+                nn.init.constant_(mod.weight, 1)
+                nn.init.constant_(mod.bias, 0)
+            elif isinstance(mod, nn.Linear):
+                nn.init.normal_(mod.weight, 0, 0.01)
+
+    def forward(self, x):
+        dev = _require_gpu(self, "AudioModel")
+        x = x.to(device=dev, dtype=torch.float32)
+        if _needs_grad(self):
+            return _BranchFn.apply(self, x, *self.parameters())
+        ws = self.__dict__.setdefault("_ws", Workspace(dev))
+        feat, _ = audio_engine.audio_forward(self, x, self.training, False, ws)
+        return feat.clone()
+
+
+class TextModel(nn.Module):
+    def __init__(self, vocab_size=30522, embedding_dim=256, filter_sizes=[3, 4, 5], num_filters=128,
+                 dropout_rate=0.3, max_length=128):
+        super().__init__()
+        self.max_length = max_length
+        self.embedding_dim = embedding_dim
+        self.embedding = nn.Embedding(vocab_size, embedding_dim, padding_idx=0)
+        self.convs = nn.ModuleList([nn.Conv1d(embedding_dim, num_filters, kernel_size=k) for k in filter_sizes])
+        self.feature_dim = len(filter_sizes) * num_filters
+        self._init_weights()
+
+    def _init_weights(self):
+        # multimodal_model.py:163-171 (the normal_ draw also overwrites the padding row)
+        nn.init.normal_(self.embedding.weight, mean=0, std=0.1)
+        for conv in self.convs:
+            nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
+            nn.init.constant_(conv.bias, 0)
+
+    def forward(self, input_ids, attention_mask=None):
+        dev = _require_gpu(self, "TextModel")
+        input_ids = input_ids.to(dev)
+        if _needs_grad(self):
+            return _BranchFn.apply(self, input_ids, *self.parameters())
+        ws = self.__dict__.setdefault("_ws", Workspace(dev))
+        feat, _ = text_engine.text_forward(self, input_ids, False, ws)
+        return feat.clone()
+
+
+class MultifactorFeatureNormalizer(nn.Module):
+    def __init__(self, audio_dim, text_dim):
+        super().__init__()
+        self.audio_norm = nn.LayerNorm(audio_dim)
+        self.text_norm = nn.LayerNorm(text_dim)
+        self.audio_scale = nn.Parameter(torch.ones(1))
+        self.text_scale = nn.Parameter(torch.ones(1))
+
+    def forward(self, audio_features, text_features):
+        _no_standalone("MultifactorFeatureNormalizer")
+
+
+class ModalityFusion(nn.Module):
+    def __init__(self, audio_dim, text_dim, hidden_dim=256, dropout_rate=0.5, audio_dropout_prob=0.3,
+                 text_dropout_prob=0.3):
+        super().__init__()
+        self.audio_projector = _stack([("lin", audio_dim, hidden_dim), ("ln", hidden_dim), ("relu",),
+                                       ("drop", dropout_rate)])
+        self.text_projector = _stack([("lin", text_dim, hidden_dim), ("ln", hidden_dim), ("relu",),
+                                      ("drop", dropout_rate)])
+        self.attention = _stack([("lin", hidden_dim * 2, 2), ("softmax",)])
+        self.output_dim = hidden_dim
+        self.audio_dropout_prob = audio_dropout_prob
+        self.text_dropout_prob = text_dropout_prob
+
+    def draw_modality_dropout(self):
+        """The reference's two host-side draws, audio first (multimodal_model.py:264-268)."""
+        if not self.training:
+            return False, False
+        da = torch.rand(1).item() < self.audio_dropout_prob
+        dt = torch.rand(1).item() < self.text_dropout_prob
+        return da, dt
+
+    def forward(self, audio_features, text_features):
+        _no_standalone("ModalityFusion")
+
+
+class _ModelFn(torch.autograd.Function):
+    """One autograd node for the whole model: forward and backward are HIP launch sequences."""
+
+    @staticmethod
+    def forward(ctx, model, audio, input_ids, labels, drops, *params):
+        run = model._run(audio, input_ids, labels, drops, need_grad=True, ws=Workspace(params[0].device, False))
+        ctx.model, ctx.run = model, run
+        ctx.set_materialize_grads(False)
+        loss = run.loss.view(()).clone() if run.loss is not None else None
+        return run.head.logits.clone(), run.head.probs.clone(), loss
+
+    @staticmethod
+    def backward(ctx, g_logits, g_probs, g_loss):
+        model, run = ctx.model, ctx.run
+        plist = list(model.parameters())
+        d = None
+        if g_loss is not None and run.head.dlogits is not None:
+            d = run.head.dlogits * g_loss
+        if g_logits is not None:
+            d = g_logits if d is None else d + g_logits
+        if g_probs is not None:
+            p = run.head.probs
+            dp = p * (g_probs - (g_probs * p).sum(dim=1, keepdim=True))
+            d = dp if d is None else d + dp
+        none = (None,) * 5
+        if d is None:
+            return none + tuple(None for _ in plist)
+        gflat = torch.empty_like(model._arena.flat)
+        views = model._arena.views_of(gflat)
+        grads = Grads({id(p): v for p, v in zip(plist, views)})
+        model._backward(run, d.contiguous(), grads)
+        if run.l2 and g_loss is not None:
+            # d/dp of 0.001 * ||p||: lambda * p / ||p|| per tensor, scaled by the incoming loss gradient
+            ops.l2_grad_add(gflat, model._arena.flat, model._arena.tnorm, L2_LAMBDA * float(g_loss), model._arena.table)
+        missing = [p for p in plist if id(p) not in run.touched]
+        for p in missing:
+            grads.of(p).zero_()
+        return none + tuple(views)
+
+
+class MultimodalSentimentModel(nn.Module):
+    def __init__(self, modality="both", num_classes=3, audio_dropout=0.5, text_dropout=0.3, fusion_dropout=0.5,
+                 vocab_size=30522, embedding_dim=256, filter_sizes=[3, 4, 5], num_filters=128, max_length=128):
+        super().__init__()
+        if modality not in ("audio", "text", "both"):
+            modality = "both" if modality is None else modality
+        self.modality = modality
+        self._dropouts = (audio_dropout, text_dropout, fusion_dropout)
+        if modality in ("audio", "both"):
+            self.audio_model = AudioModel(num_classes=num_classes, dropout_rate=audio_dropout)
+            self.audio_feature_dim = self.audio_model.feature_dim
+        else:
+            self.audio_model = None
+            self.audio_feature_dim = 0
+        if modality in ("text", "both"):
+            self.text_model = TextModel(vocab_size=vocab_size, embedding_dim=embedding_dim, filter_sizes=filter_sizes,
+                                        num_filters=num_filters, dropout_rate=text_dropout, max_length=max_length)
+            self.text_feature_dim = self.text_model.feature_dim
+        else:
+            self.text_model = None
+            self.text_feature_dim = 0
+        if modality == "both":
+            self.feature_normalizer = MultifactorFeatureNormalizer(self.audio_feature_dim, self.text_feature_dim)
+            self.fusion_layer = ModalityFusion(self.audio_feature_dim, self.text_feature_dim, hidden_dim=256,
+                                               dropout_rate=fusion_dropout)
+            self.fusion_dim = self.fusion_layer.output_dim
+        else:
+            self.fusion_dim = self.audio_feature_dim + self.text_feature_dim
+        d = self.fusion_dim
+        if modality == "audio":
+            p = audio_dropout
+            spec = [("flat",), ("lin", d, 128), ("bn1", 128), ("relu",), ("drop", p), ("lin", 128, 64), ("bn1", 64),
+                    ("relu",), ("drop", p / 2), ("lin", 64, num_classes)]
+        elif modality == "text":
+            p = text_dropout
+            spec = [("drop", p), ("lin", d, 256), ("relu",), ("ln", 256), ("drop", p), ("lin", 256, 128), ("relu",),
+                    ("ln", 128), ("drop", p), ("lin", 128, num_classes)]
+        else:
+            p = fusion_dropout
+            spec = [("lin", d, 128), ("ln", 128), ("relu",), ("drop", p), ("lin", 128, 64), ("ln", 64), ("relu",),
+                    ("drop", p / 2), ("lin", 64, num_classes)]
+        self.classifier = _stack(spec)
+        self.loss_fn = nn.CrossEntropyLoss()
+        self._arena: Optional[ParamArena] = None
+        self._seed_counter = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _ensure_arena(self) -> ParamArena:
+        dev = _require_gpu(self, "MultimodalSentimentModel")
+        a = self.__dict__.get("_arena")
+        if a is None or a.device != dev or not a.owns():
+            for p in self.parameters():
+                if p.dtype != torch.float32:
+                    raise TypeError("the HIP kernels compute in float32; convert the model with .float()")
+            a = ParamArena(list(self.parameters()), dev)
+            self.__dict__["_arena"] = a
+            self.__dict__["_ws_infer"] = Workspace(dev)
+            self.__dict__["_consts"] = {1: torch.ones(1, device=dev), 0: torch.zeros(1, device=dev)}
+        return a
+
+    def _drop_p(self):
+        return {"audio": self._dropouts[0], "text": self._dropouts[1], "both": self._dropouts[2]}[self.modality]
+
+    def _next_seed(self):
+        self.__dict__["_seed_counter"] = self.__dict__.get("_seed_counter", 0) + 1
+        return (torch.initial_seed() * 1000003 + self._seed_counter * 97) & ((1 << 62) - 1)
+
+    def _check_inputs(self, audio, input_ids):
+        if self.modality == "audio" and audio is None:
+            raise ValueError("Audio input is required for audio modality")
+        if self.modality == "text" and input_ids is None:
+            raise ValueError("Text input is required for text modality")
+        if self.modality == "both" and (audio is None or input_ids is None):
+            raise ValueError("Both audio and text inputs are required for multimodal fusion")
+
+    def _run(self, audio, input_ids, labels, drops, need_grad, ws, keep=None, logits_out=None):
+        """Forward launch sequence.  Returns a record with the head state, branch states and the loss buffer."""
+        from types import SimpleNamespace
+        arena = self._arena
+        training = self.training
+        run = SimpleNamespace(audio=None, text=None, l2=False, touched=set())
+        a_feat = t_feat = None
+        if self.modality in ("audio", "both"):
+            a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, self.audio_model.training,
+                                                           need_grad, ws)
+        if self.modality in ("text", "both"):
+            t_feat, run.text = text_engine.text_forward(self.text_model, input_ids, need_grad, ws)
+        seed = self._next_seed() if training and self._drop_p() > 0 else 0
+        if self.modality == "both":
+            if keep is None:
+                c = self._consts
+                keep = (c[0] if drops[0] else c[1], c[0] if drops[1] else c[1])
+            run.head = head_engine.head_forward_both(self, a_feat, t_feat, labels, training, keep[0], keep[1],
+                                                     self._drop_p(), seed, need_grad, ws, logits_out)
+        elif self.modality == "audio":
+            run.head = head_engine.head_forward_audio(self, a_feat, labels, training, self._drop_p(), seed, need_grad,
+                                                      ws, logits_out)
+        else:
+            run.head = head_engine.head_forward_text(self, t_feat, labels, training, self._drop_p(), seed, need_grad,
+                                                     ws, logits_out)
+        run.loss = run.head.loss
+        if labels is not None and self.modality == "both" and run.head.loss is not None:
+            run.l2 = True
+            psum = ws.buf("loss.psum", 1)
+            ops.param_norms(arena.flat, arena.table, arena.tnorm, psum)
+            run.loss = ws.buf("loss.total", 1)
+            ops.scalar_axpy(run.loss, run.head.loss, psum, L2_LAMBDA)
+        if need_grad:
+            run.touched = {id(p) for p in self.parameters()}
+        return run
+
+    def _backward(self, run, dlogits, grads: Grads, ws: Optional[Workspace] = None):
+        ws = ws or Workspace(dlogits.device, persistent=False)
+        if self.modality == "both":
+            d_a, d_t = head_engine.head_backward_both(self, run.head, dlogits, grads, ws)
+            text_engine.text_backward(self.text_model, run.text, d_t, grads)
+            audio_engine.audio_backward(self.audio_model, run.audio, d_a, self.audio_model.training, grads, ws)
+        elif self.modality == "audio":
+            d_a = head_engine.head_backward_audio(self, run.head, dlogits, grads, ws)
+            audio_engine.audio_backward(self.audio_model, run.audio, d_a, self.audio_model.training, grads, ws)
+        else:
+            d_t = head_engine.head_backward_text(self, run.head, dlogits, grads, ws)
+            text_engine.text_backward(self.text_model, run.text, d_t, grads)
+
+    # ------------------------------------------------------------------ the reference's forward signature
+    def forward(self, audio=None, input_ids=None, attention_mask=None, labels=None):
+        self._check_inputs(audio, input_ids)
+        arena = self._ensure_arena()
+        dev = arena.device
+        if audio is not None and self.modality != "text":
+            audio = audio.to(device=dev, dtype=torch.float32)
+        if input_ids is not None and self.modality != "audio":
+            input_ids = input_ids.to(dev)
+        if labels is not None:
+            labels = labels.to(dev)
+        drops = (False, False)
+        if self.modality == "both":
+            drops = self.fusion_layer.draw_modality_dropout()
+        if _needs_grad(self):
+            logits, probs, loss = _ModelFn.apply(self, audio, input_ids, labels, drops, *self.parameters())
+            return {"loss": loss, "logits": logits, "probabilities": probs}
+        return self._infer(audio, input_ids, labels, drops)
+
+    def _infer(self, audio, input_ids, labels, drops):
+        """No-grad path.  Eval-mode batches are processed in chunks (BatchNorm uses running statistics there,
+        so chunking is exact); train-mode batches go through whole because the batch statistics need them."""
+        ws = self._ws_infer
+        B = audio.shape[0] if audio is not None and self.modality != "text" else input_ids.shape[0]
+        ncls = self.classifier[-1].weight.shape[0]
+        logits = torch.empty((B, ncls), dtype=torch.float32, device=self._arena.device)
+        chunk = B if self.training else INFER_CHUNK
+        for i0 in range(0, B, chunk):
+            i1 = min(B, i0 + chunk)
+            a = audio[i0:i1] if audio is not None and self.modality != "text" else None
+            t = input_ids[i0:i1] if input_ids is not None and self.modality != "audio" else None
+            self._run(a, t, None, drops, need_grad=False, ws=ws, logits_out=logits[i0:i1])
+        probs = torch.empty_like(logits)
+        loss = None
+        ce = torch.empty(1, dtype=torch.float32, device=logits.device) if labels is not None else None
+        lab = None
+        if labels is not None:
+            lab = labels.contiguous().to(torch.int64)
+        ops.softmax_ce(logits, lab, probs, ce, None)
+        if labels is not None:
+            loss = ce
+            if self.modality == "both":
+                psum = torch.empty(1, dtype=torch.float32, device=logits.device)
+                ops.param_norms(self._arena.flat, self._arena.table, self._arena.tnorm, psum)
+                loss = torch.empty_like(ce)
+                ops.scalar_axpy(loss, ce, psum, L2_LAMBDA)
+            loss = loss.view(())
+        return {"loss": loss, "logits": logits, "probabilities": probs}
+
+
+class FocalLoss(nn.Module):
+    """multimodal_model.py:468-480.  The reference's drivers construct it but never call it
+    (`multimodal_train.py:145-217` ignores ``criterion``), so it stays a plain composition of torch ops."""
+
+    def __init__(self, alpha=None, gamma=2.0, reduction="mean"):
+        super().__init__()
+        self.alpha = alpha
+        self.gamma = gamma
+        self.reduction = reduction
+        self.ce_loss = nn.CrossEntropyLoss(weight=alpha, reduction="none")
+
+    def forward(self, inputs, targets):
+        ce = self.ce_loss(inputs, targets)
+        focal = (1 - torch.exp(-ce)) ** self.gamma * ce
+        return focal.mean() if self.reduction == "mean" else focal.sum()

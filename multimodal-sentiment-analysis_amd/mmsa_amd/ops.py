@@ -1,0 +1,387 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per entry point family).
+
+Every wrapper checks device / dtype / contiguity and the shapes the kernels assume before launching, then
+enqueues on torch's current HIP stream.  No wrapper computes anything itself and none has a fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+F32 = torch.float32
+EPI_NONE, EPI_LN_RELU, EPI_RELU_LN, EPI_RELU = 0, 1, 2, 3
+BN_MOMENTUM, BN_EPS = 0.1, 1e-5
+
+TAPS3X3 = [(dh, dw) for dh in (-1, 0, 1) for dw in (-1, 0, 1)]   # kernel index kh*3+kw -> offset (kh-1, kw-1)
+TAPS1X1 = [(0, 0)]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype=F32, name: str = "tensor") -> int:
+    if not t.is_cuda:
+        raise _lib.MmsaError(f"{name} must live on the GPU (the HIP kernels have no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], dtype=F32, name: str = "tensor"):
+    return None if t is None else _chk(t, dtype, name)
+
+
+def _iarr(vals: Sequence[int]):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def _parr(ptrs: Sequence[int]):
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+# ---------------------------------------------------------------------------------------------- front end
+def logmel(wave: torch.Tensor, tables, out: torch.Tensor, n_target: int = 66150, top_db: float = 80.0):
+    """wave [B, n] -> out [B, 1, 64, 1 + n_target // 512]."""
+    if wave.dim() != 2:
+        raise ValueError("wave must be [B, n_samples]")
+    B, n = wave.shape
+    frames = 1 + n_target // 512
+    if tuple(out.shape) != (B, 1, 64, frames):
+        raise ValueError(f"out must be [{B},1,64,{frames}]")
+    if wave.stride(1) != 1:
+        raise ValueError("wave rows must be contiguous")
+    if not wave.is_cuda or wave.dtype != F32:
+        raise _lib.MmsaError("wave must be a float32 GPU tensor")
+    _lib.call("mmsa_logmel_fwd", wave.data_ptr(), wave.stride(0), n, n_target, B, _chk(tables["window"]),
+              _chk(tables["tw512"]), _chk(tables["tw1024"]), _chk(tables["melfb"]),
+              _chk(tables["melrange"], torch.int32), top_db, _chk(out), _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- convolution
+def pack_weights(w: torch.Tensor, fwd: Optional[torch.Tensor], dgrad: Optional[torch.Tensor]):
+    cout, cin = w.shape[0], w.shape[1]
+    ntaps = w.numel() // (cout * cin)
+    for t in (fwd, dgrad):
+        if t is not None and t.numel() != w.numel():
+            raise ValueError("packed buffer size mismatch")
+    _lib.call("mmsa_conv_pack_weights", _chk(w), _opt(fwd), _opt(dgrad), cout, cin, ntaps, _stream())
+
+
+def conv_tile_rows(B, H, W, Cout) -> int:
+    return _lib.query("mmsa_conv_tile_rows", B, H, W, Cout)
+
+
+def conv_stats_rows(B, H, W, Cout):
+    bm = conv_tile_rows(B, H, W, Cout)
+    tiles = (H * W + bm - 1) // bm
+    return B * tiles, tiles
+
+
+def conv_fwd(X, Wp, Y, stats, B, H, W, Cin, Cout, taps, negate=False, accumulate=False):
+    if X.numel() != B * H * W * Cin or Y.numel() != B * H * W * Cout or Wp.numel() != len(taps) * Cin * Cout:
+        raise ValueError("conv_fwd: operand sizes do not match the geometry")
+    if stats is not None:
+        rows, _ = conv_stats_rows(B, H, W, Cout)
+        if stats.numel() != rows * 2 * Cout:
+            raise ValueError("conv_fwd: stats buffer has the wrong size")
+    sgn = -1 if negate else 1
+    _lib.call("mmsa_conv_fwd", _chk(X), _chk(Wp), _chk(Y), _opt(stats), B, H, W, Cin, Cout, len(taps),
+              _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), int(accumulate), _stream())
+
+
+def conv_wgrad_workspace(B, H, W, Cin, Cout, ntaps) -> int:
+    return _lib.query("mmsa_conv_wgrad_workspace_floats", B, H, W, Cin, Cout, ntaps, None)
+
+
+def conv_wgrad(X, dY, dW, workspace, B, H, W, Cin, Cout, taps, w_valid=None, accumulate=False):
+    if X.numel() != B * H * W * Cin or dY.numel() != B * H * W * Cout or dW.numel() != len(taps) * Cin * Cout:
+        raise ValueError("conv_wgrad: operand sizes do not match the geometry")
+    if workspace.numel() < conv_wgrad_workspace(B, H, W, Cin, Cout, len(taps)):
+        raise ValueError("conv_wgrad: workspace too small")
+    _lib.call("mmsa_conv_wgrad", _chk(X), _chk(dY), _chk(dW), _chk(workspace), B, H, W,
+              W if w_valid is None else w_valid, Cin, Cout, len(taps), _iarr([t[0] for t in taps]),
+              _iarr([t[1] for t in taps]), int(accumulate), _stream())
+
+
+# ---------------------------------------------------------------------------------------------- audio branch
+def stem_stats(x, w, bias, partial, B, H, W):
+    if x.numel() != B * H * W or partial.numel() != B * H * 64 or w.numel() != 288 or bias.numel() != 32:
+        raise ValueError("stem_stats: bad sizes")
+    _lib.call("mmsa_stem_stats", _chk(x), _chk(w), _chk(bias), _chk(partial), B, H, W, _stream())
+
+
+def stem_apply_pool(x, w, bias, coeff, out, B, H, W):
+    if x.numel() != B * H * W or out.numel() != B * (H // 2) * (W // 2) * 32 or coeff.numel() != 128:
+        raise ValueError("stem_apply_pool: bad sizes")
+    _lib.call("mmsa_stem_apply_pool", _chk(x), _chk(w), _chk(bias), _chk(coeff), _chk(out), B, H, W, _stream())
+
+
+def stem_bwd_scratch(B, H) -> int:
+    return B * (H // 2) * 384 + 64
+
+
+def stem_bwd(x, w, bias, coeff, dout, dW, dbias, dgamma, dbeta, scratch, B, H, W, training):
+    if dout.numel() != B * (H // 2) * (W // 2) * 32 or scratch.numel() < stem_bwd_scratch(B, H):
+        raise ValueError("stem_bwd: bad sizes")
+    if dW.numel() != 288 or dbias.numel() != 32 or dgamma.numel() != 32 or dbeta.numel() != 32:
+        raise ValueError("stem_bwd: bad gradient sizes")
+    _lib.call("mmsa_stem_bwd", _chk(x), _chk(w), _chk(bias), _chk(coeff), _chk(dout), _chk(dW), _chk(dbias),
+              _chk(dgamma), _chk(dbeta), _chk(scratch), B, H, W, int(training), _stream())
+
+
+def bn_finalize(partial, rows, tiles_per_img, count, gamma, beta, rmean, rvar, nbt, training, coeff, bsum, C):
+    if coeff.numel() != 4 * C or gamma.numel() != C:
+        raise ValueError("bn_finalize: bad sizes")
+    if partial is not None and partial.numel() != rows * 2 * C:
+        raise ValueError("bn_finalize: partial buffer has the wrong size")
+    if bsum is not None and bsum.numel() != (rows // tiles_per_img) * C:
+        raise ValueError("bn_finalize: bsum has the wrong size")
+    _lib.call("mmsa_bn_finalize", _opt(partial), rows, tiles_per_img, float(count), _chk(gamma), _chk(beta),
+              _opt(rmean), _opt(rvar), _opt(nbt, torch.int64), BN_MOMENTUM, BN_EPS, int(training), _chk(coeff),
+              _opt(bsum), C, _stream())
+
+
+def bn_relu_apply(x, coeff, y, npos, C):
+    if x.numel() != npos * C or y.numel() != npos * C or coeff.numel() != 4 * C:
+        raise ValueError("bn_relu_apply: bad sizes")
+    _lib.call("mmsa_bn_relu_apply", _chk(x), _chk(coeff), _chk(y), npos, C, _stream())
+
+
+def se_gate(bsum, coeff, W1, W2, HW, gap, hid, gate, B, C):
+    Ch = W1.shape[0]
+    if W1.numel() != Ch * C or W2.numel() != C * Ch or bsum.numel() != B * C or gate.numel() != B * C \
+            or gap.numel() != B * C or hid.numel() != B * Ch:
+        raise ValueError("se_gate: bad sizes")
+    _lib.call("mmsa_se_gate", _chk(bsum), _chk(coeff), _chk(W1), _chk(W2), HW, _chk(gap), _chk(hid), _chk(gate),
+              B, C, Ch, _stream())
+
+
+def res_gate_relu_pool(c2, sc, coeff2, coeffs, gate, out, B, H, W, C):
+    n = B * H * W * C
+    if c2.numel() != n or sc.numel() != n or out.numel() != B * (H // 2) * (W // 2) * C or gate.numel() != B * C:
+        raise ValueError("res_gate_relu_pool: bad sizes")
+    _lib.call("mmsa_res_gate_relu_pool", _chk(c2), _chk(sc), _chk(coeff2), _chk(coeffs), _chk(gate), _chk(out),
+              B, H, W, C, _stream())
+
+
+def gap_fwd(x, out, B, P, C):
+    if x.numel() != B * P * C or out.numel() != B * C:
+        raise ValueError("gap_fwd: bad sizes")
+    _lib.call("mmsa_gap_fwd", _chk(x), _chk(out), B, P, C, _stream())
+
+
+def gap_bwd(dout, dx, B, P, C):
+    if dx.numel() != B * P * C or dout.numel() != B * C:
+        raise ValueError("gap_bwd: bad sizes")
+    _lib.call("mmsa_gap_bwd", _chk(dout), _chk(dx), B, P, C, _stream())
+
+
+def resblock_bwd_scratch(B, H, W, C) -> int:
+    return _lib.query("mmsa_resblock_bwd_scratch_floats", B, H, W, C)
+
+
+def resblock_bwd_ew(dout, c2, sc, coeff2, coeffs, gate, hid, gap, bsum, W1, W2, d_c2, d_sc, dgamma2, dbeta2,
+                    dgammas, dbetas, dW1, dW2, scratch, B, H, W, C, training):
+    n = B * H * W * C
+    if dout.numel() != B * (H // 2) * (W // 2) * C or c2.numel() != n or sc.numel() != n or d_c2.numel() != n \
+            or d_sc.numel() != n or scratch.numel() < resblock_bwd_scratch(B, H, W, C):
+        raise ValueError("resblock_bwd_ew: bad sizes")
+    for t in (dgamma2, dbeta2, dgammas, dbetas):
+        if t.numel() != C:
+            raise ValueError("resblock_bwd_ew: bad BN gradient size")
+    if dW1.numel() != W1.numel() or dW2.numel() != W2.numel():
+        raise ValueError("resblock_bwd_ew: bad SE gradient size")
+    _lib.call("mmsa_resblock_bwd_ew", _chk(dout), _chk(c2), _chk(sc), _chk(coeff2), _chk(coeffs), _chk(gate),
+              _chk(hid), _chk(gap), _chk(bsum), _chk(W1), _chk(W2), _chk(d_c2), _chk(d_sc), _chk(dgamma2),
+              _chk(dbeta2), _chk(dgammas), _chk(dbetas), _chk(dW1), _chk(dW2), _chk(scratch), B, H, W, C,
+              int(training), _stream())
+
+
+def bn_relu_bwd_scratch(npos, C) -> int:
+    return _lib.query("mmsa_bn_relu_bwd_scratch_floats", npos, C)
+
+
+def bn_relu_bwd(dh, c1, coeff, dgamma, dbeta, scratch, npos, C, training):
+    if dh.numel() != npos * C or c1.numel() != npos * C or scratch.numel() < bn_relu_bwd_scratch(npos, C):
+        raise ValueError("bn_relu_bwd: bad sizes")
+    _lib.call("mmsa_bn_relu_bwd", _chk(dh), _chk(c1), _chk(coeff), _chk(dgamma), _chk(dbeta), _chk(scratch), npos, C,
+              int(training), _stream())
+
+
+# ---------------------------------------------------------------------------------------------- text branch
+def embedding_gather(ids, table, out, err=None):
+    ntok = ids.numel()
+    V, E = table.shape
+    if out.numel() != ntok * E:
+        raise ValueError("embedding_gather: bad output size")
+    _lib.call("mmsa_embedding_gather", _chk(ids, torch.int64, "input_ids"), _chk(table), _chk(out), ntok, E, V,
+              _opt(err, torch.int32), _stream())
+
+
+def bias_relu_maxtime(y, bias, feat, arg, B, L, Lout, F, ldf, col0):
+    if y.numel() != B * L * F or feat.shape != (B, ldf) or arg.shape != (B, ldf) or col0 + F > ldf:
+        raise ValueError("bias_relu_maxtime: bad sizes")
+    _chk(feat), _chk(arg, torch.int32)
+    _lib.call("mmsa_bias_relu_maxtime", _chk(y), _chk(bias), feat.data_ptr() + 4 * col0, arg.data_ptr() + 4 * col0,
+              B, L, Lout, F, ldf, _stream())
+
+
+def text_bwd(dfeat, feat, arg, emb, ids, ksizes, wps, dWs, dbs, dtable, B, L, E, F, padding_idx=0):
+    n = len(ksizes)
+    ldf = n * F
+    if dfeat.shape != (B, ldf) or feat.shape != (B, ldf) or arg.shape != (B, ldf) or emb.numel() != B * L * E:
+        raise ValueError("text_bwd: bad sizes")
+    for k, wp, dW, db in zip(ksizes, wps, dWs, dbs):
+        if wp.numel() != k * F * E or dW.numel() != k * F * E or db.numel() != F:
+            raise ValueError("text_bwd: bad weight sizes")
+    _lib.call("mmsa_text_bwd", _chk(dfeat), _chk(feat), _chk(arg, torch.int32), _chk(emb),
+              _chk(ids, torch.int64), n, _iarr(ksizes), _iarr([i * F for i in range(n)]),
+              _parr([_chk(w) for w in wps]), _parr([_chk(w) for w in dWs]), _parr([_chk(w) for w in dbs]),
+              _chk(dtable), B, L, E, F, ldf, padding_idx, _stream())
+
+
+# ---------------------------------------------------------------------------------------------- dense head
+def _rows(t: torch.Tensor, name: str):
+    """2-D row view: (pointer, leading dimension); rows must be unit-stride."""
+    if t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda or t.dtype != F32:
+        raise ValueError(f"{name}: need a float32 GPU matrix with unit-stride rows")
+    return t.data_ptr(), t.stride(0)
+
+
+def dense_fwd(X, W, bias, gamma, beta, Y, pre, stats, epilogue=EPI_NONE, drop_p=0.0, seed=0):
+    B, K = X.shape
+    N = W.shape[0]
+    if W.shape != (N, K) or Y.shape != (B, N):
+        raise ValueError("dense_fwd: shape mismatch")
+    xp, ldx = _rows(X, "X")
+    yp, ldy = _rows(Y, "Y")
+    if pre is not None and pre.numel() != B * N:
+        raise ValueError("dense_fwd: bad pre size")
+    if stats is not None and stats.numel() != 2 * B:
+        raise ValueError("dense_fwd: bad stats size")
+    _lib.call("mmsa_dense_fwd", xp, ldx, _chk(W), _opt(bias), _opt(gamma), _opt(beta), yp, ldy, _opt(pre), _opt(stats),
+              B, K, N, epilogue, float(drop_p), int(seed), _stream())
+
+
+def dense_bwd(dY, X, pre, stats, W, gamma, beta, dPre, dLn, dX, dW, db, dgamma, dbeta, epilogue=EPI_NONE, drop_p=0.0,
+              seed=0, accumulate_dx=False):
+    B, K = X.shape
+    N = W.shape[0]
+    if dY.shape != (B, N) or dPre.numel() != B * N:
+        raise ValueError("dense_bwd: shape mismatch")
+    dyp, ldy = _rows(dY, "dY")
+    xp, ldx = _rows(X, "X")
+    dxp, lddx = (None, 0) if dX is None else _rows(dX, "dX")
+    if dX is not None and dX.shape != (B, K):
+        raise ValueError("dense_bwd: bad dX shape")
+    if dW is not None and (dW.numel() != N * K or db is None or db.numel() != N):
+        raise ValueError("dense_bwd: bad dW/db")
+    _lib.call("mmsa_dense_bwd", dyp, ldy, xp, ldx, _opt(pre), _opt(stats), _chk(W), _opt(gamma), _opt(beta), _chk(dPre),
+              _opt(dLn), dxp, lddx, _opt(dW), _opt(db), _opt(dgamma), _opt(dbeta), B, K, N, epilogue, float(drop_p),
+              int(seed), int(accumulate_dx), _stream())
+
+
+def ln_scale_fwd(x, gamma, beta, scale, keep, y, stats):
+    B, N = x.shape
+    yp, ldy = _rows(y, "y")
+    if y.shape != (B, N) or stats.numel() != 2 * B:
+        raise ValueError("ln_scale_fwd: bad sizes")
+    _lib.call("mmsa_ln_scale_fwd", _chk(x), _chk(gamma), _chk(beta), _chk(scale), _opt(keep), yp, ldy, _chk(stats), B, N,
+              _stream())
+
+
+def ln_scale_bwd(dy, x, gamma, beta, scale, keep, stats, dx, dgamma, dbeta, dscale, scratch):
+    B, N = x.shape
+    dyp, ldy = _rows(dy, "dy")
+    if dy.shape != (B, N) or dx.numel() != B * N or scratch.numel() < B * N + B:
+        raise ValueError("ln_scale_bwd: bad sizes")
+    _lib.call("mmsa_ln_scale_bwd", dyp, ldy, _chk(x), _chk(gamma), _chk(beta), _chk(scale), _opt(keep), _chk(stats),
+              _chk(dx), _chk(dgamma), _chk(dbeta), _chk(dscale), _chk(scratch), B, N, _stream())
+
+
+def fusion_mix_fwd(P, att, wts, fused):
+    B, H2 = P.shape
+    if att.shape != (B, 2) or wts.numel() != 2 * B or fused.shape != (B, H2 // 2):
+        raise ValueError("fusion_mix_fwd: bad sizes")
+    _lib.call("mmsa_fusion_mix_fwd", _chk(P), _chk(att), _chk(wts), _chk(fused), B, H2 // 2, _stream())
+
+
+def fusion_mix_bwd(dfused, P, wts, dP, datt):
+    B, H2 = P.shape
+    if dfused.shape != (B, H2 // 2) or dP.shape != (B, H2) or datt.numel() != 2 * B:
+        raise ValueError("fusion_mix_bwd: bad sizes")
+    _lib.call("mmsa_fusion_mix_bwd", _chk(dfused), _chk(P), _chk(wts), _chk(dP), _chk(datt), B, H2 // 2, _stream())
+
+
+def softmax_ce(logits, labels, probs, loss, dlogits):
+    B, C = logits.shape
+    if probs.shape != (B, C) or (dlogits is not None and dlogits.shape != (B, C)):
+        raise ValueError("softmax_ce: bad sizes")
+    if labels is not None and labels.numel() != B:
+        raise ValueError("softmax_ce: bad labels size")
+    _lib.call("mmsa_softmax_ce", _chk(logits), _opt(labels, torch.int64, "labels"), _chk(probs), _opt(loss),
+              _opt(dlogits), B, C, _stream())
+
+
+def bn1d_relu_fwd(x, gamma, beta, rmean, rvar, nbt, training, y, coeff, drop_p=0.0, seed=0):
+    B, N = x.shape
+    if y.shape != (B, N) or coeff.numel() != 4 * N:
+        raise ValueError("bn1d_relu_fwd: bad sizes")
+    _lib.call("mmsa_bn1d_relu_fwd", _chk(x), _chk(gamma), _chk(beta), _chk(rmean), _chk(rvar), _opt(nbt, torch.int64),
+              BN_MOMENTUM, BN_EPS, int(training), _chk(y), _chk(coeff), B, N, float(drop_p), int(seed), _stream())
+
+
+def bn1d_relu_bwd(dy, x, coeff, dx, dgamma, dbeta, training, drop_p=0.0, seed=0):
+    B, N = x.shape
+    if dy.shape != (B, N) or dx.shape != (B, N):
+        raise ValueError("bn1d_relu_bwd: bad sizes")
+    _lib.call("mmsa_bn1d_relu_bwd", _chk(dy), _chk(x), _chk(coeff), _chk(dx), _chk(dgamma), _chk(dbeta), B, N,
+              int(training), float(drop_p), int(seed), _stream())
+
+
+def dropout(x, y, drop_p, seed):
+    if x.numel() != y.numel():
+        raise ValueError("dropout: size mismatch")
+    _lib.call("mmsa_dropout", _chk(x), _chk(y), x.numel(), float(drop_p), int(seed), _stream())
+
+
+# ---------------------------------------------------------------------------------------------- optimiser
+def param_norms(flat, table, tnorm, sum_out):
+    _lib.call("mmsa_param_norms", _chk(flat), _chk(table.chunk_off, torch.int64), _chk(table.chunk_len, torch.int32),
+              _chk(table.chunk_tensor, torch.int32), table.nchunks, _chk(table.tensor_first_chunk, torch.int32),
+              table.ntensors, _chk(table.chunk_ss, torch.float64), _chk(tnorm), _opt(sum_out), _stream())
+
+
+def l2_grad_add(gflat, pflat, tnorm, lam, table):
+    _lib.call("mmsa_l2_grad_add", _chk(gflat), _chk(pflat), _chk(tnorm), float(lam), _chk(table.chunk_off, torch.int64),
+              _chk(table.chunk_len, torch.int32), _chk(table.chunk_tensor, torch.int32), table.nchunks, _stream())
+
+
+def grad_norm(gflat, table, state):
+    _lib.call("mmsa_grad_norm", _chk(gflat), _chk(table.chunk_off, torch.int64), _chk(table.chunk_len, torch.int32),
+              _chk(table.chunk_tensor, torch.int32), table.nchunks, _chk(table.tensor_first_chunk, torch.int32),
+              table.ntensors, _chk(table.chunk_ss, torch.float64), _chk(state), _stream())
+
+
+def adamw_step(p, g, m, v, state, lr, beta1, beta2, eps, wd, max_norm, do_clip):
+    n = p.numel()
+    if g.numel() != n or m.numel() != n or v.numel() != n or state.numel() < 8:
+        raise ValueError("adamw_step: size mismatch")
+    _lib.call("mmsa_adamw_step", _chk(p), _chk(g), _chk(m), _chk(v), n, _chk(state), float(lr), float(beta1),
+              float(beta2), float(eps), float(wd), float(max_norm), int(do_clip), _stream())
+
+
+def scale_by_state(g, state, idx):
+    _lib.call("mmsa_scale_by_state", _chk(g), g.numel(), _chk(state), idx, _stream())
+
+
+def scalar_axpy(dst, a, b, alpha):
+    _lib.call("mmsa_scalar_axpy", _chk(dst), _chk(a), _chk(b), float(alpha), _stream())

@@ -1,0 +1,55 @@
+"""Text branch: launch sequences (gather -> per-width conv -> bias+ReLU+max over time) and the sparse backward.
+
+Computes what `CNN implementation/multimodal_model.py:173-199` (TextModel.forward) computes; the attention
+mask takes no part in the arithmetic there, so it is accepted and ignored here too.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+
+import torch
+
+from . import ops
+from .workspace import Grads, Workspace
+
+
+def text_forward(m, input_ids: torch.Tensor, need_grad: bool, ws: Workspace):
+    if input_ids.dim() != 2:
+        raise ValueError("input_ids must be [B, L]")
+    ids = input_ids.contiguous()
+    if ids.dtype != torch.int64:
+        ids = ids.to(torch.int64)
+    B, L = ids.shape
+    table = m.embedding.weight
+    V, E = table.shape
+    ksizes = [c.weight.shape[2] for c in m.convs]
+    F = m.convs[0].weight.shape[0]
+    if E % 32 or F % 64 or any(c.weight.shape[0] != F for c in m.convs):
+        raise NotImplementedError("HIP text branch needs embedding_dim % 32 == 0 and num_filters % 64 == 0")
+    if max(ksizes) > 7 or min(ksizes) < 2 or L < max(ksizes):
+        raise NotImplementedError("HIP text branch supports filter sizes 2..7 and sequences at least that long")
+    st = SimpleNamespace(B=B, L=L, E=E, F=F, ksizes=ksizes, ids=ids)
+    st.emb = ws.buf("text.emb", (B, L, E))
+    st.err = ws.buf("text.err", 1, torch.int32)
+    ops.embedding_gather(ids, table, st.emb, st.err)
+    n = len(ksizes)
+    st.feat = ws.buf("text.feat", (B, n * F))
+    st.arg = ws.buf("text.arg", (B, n * F), torch.int32)
+    st.wps = []
+    for i, (conv, k) in enumerate(zip(m.convs, ksizes)):
+        wp = ws.buf(f"text.wp{i}", conv.weight.numel())
+        ops.pack_weights(conv.weight, wp, None)
+        st.wps.append(wp)
+        y = ws.buf(f"text.y{i}", (B, L, F))
+        ops.conv_fwd(st.emb, wp, y, None, B, 1, L, E, F, [(0, j) for j in range(k)])
+        ops.bias_relu_maxtime(y, conv.bias, st.feat, st.arg, B, L, L - k + 1, F, n * F, i * F)
+    return st.feat, st
+
+
+def text_backward(m, st, dfeat: torch.Tensor, grads: Grads):
+    table = m.embedding.weight
+    dtable = grads.of(table)
+    dtable.zero_()    # the kernel scatter-adds token rows into it
+    ops.text_bwd(dfeat.contiguous(), st.feat, st.arg, st.emb, st.ids, st.ksizes, st.wps,
+                 [grads.of(c.weight) for c in m.convs], [grads.of(c.bias) for c in m.convs], dtable,
+                 st.B, st.L, st.E, st.F, padding_idx=m.embedding.padding_idx if m.embedding.padding_idx is not None else -1)

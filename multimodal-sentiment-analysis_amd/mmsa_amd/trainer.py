@@ -1,0 +1,160 @@
+"""Fused training step: front end -> forward -> backward -> (all-reduce) -> clip -> AdamW, no autograd.
+
+Same step as the reference's loop body (`CNN implementation/multimodal_train.py:175-202`): zero grads, forward
+with labels, backward, ``clip_grad_norm_(1.0)``, ``AdamW.step`` (lr / weight decay from `:481-485`), but
+
+* gradients are written straight into one flat buffer (nothing to zero except the embedding rows),
+* the L2 regulariser's gradient, the global-norm clip and AdamW are a few launches over flat buffers,
+* no value is read back to the host inside the step: the loss, the clip coefficient, the step count and the two
+  modality-dropout switches live in device memory, so the whole step can be captured in a HIP graph and
+  replayed (``use_graph=True``) -- the reference synchronises three times per step (`:198-202`),
+* with ``torch.distributed`` initialised (one process per GPU, backend "nccl" = RCCL), utterances are sharded
+  across ranks and the flat gradient is summed with one all-reduce per bucket; the L2 term is a function of the
+  replicated parameters, so its gradient is added locally after the reduction and never communicated.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .model import L2_LAMBDA, MultimodalSentimentModel
+from .workspace import Grads, Workspace
+
+
+class TrainStep:
+    def __init__(self, model: MultimodalSentimentModel, lr: float = 1e-3, weight_decay: float = 1e-4,
+                 betas=(0.9, 0.999), eps: float = 1e-8, max_norm: Optional[float] = 1.0, frontend=None,
+                 use_graph: bool = False, process_group=None, bucket_mb: float = 16.0):
+        self.model = model
+        self.arena = model._ensure_arena()
+        dev = self.arena.device
+        self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        self.g = self.arena.like()
+        self.m = self.arena.like()
+        self.v = self.arena.like()
+        self.state = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.grads = Grads({id(p): v for p, v in zip(self.arena.params, self.arena.views_of(self.g))})
+        self.ws = Workspace(dev, persistent=True)
+        self.frontend = frontend
+        self.keep = torch.ones(2, dtype=torch.float32, device=dev)
+        self._keep_table = torch.tensor([[1., 1.], [0., 1.], [1., 0.], [0., 0.]], device=dev)
+        self.use_graph = use_graph
+        self._graph = None
+        self._static = {}
+        self._warm = 0
+        self.loss = None
+        self.logits = None
+        self.world = 1
+        self.pg = process_group
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.world = torch.distributed.get_world_size(process_group)
+        n = self.g.numel()
+        per = max(int(bucket_mb * 1024 * 1024 / 4), 1)
+        self._buckets = [(i, min(n, i + per)) for i in range(0, n, per)]
+        if use_graph and model.training and model._drop_p() > 0:
+            raise ValueError("graph replay would repeat the same dropout masks every step; use use_graph=False "
+                             "when dropout is active")
+
+    # ------------------------------------------------------------------ one step's launch sequence
+    def _body(self, audio, input_ids, labels, wave):
+        model = self.model
+        if wave is not None:
+            audio = self.ws.buf("step.spec", (wave.shape[0], 1, 64, 130))
+            self.frontend(wave, out=audio)
+        run = model._run(audio, input_ids, labels, None, need_grad=True, ws=self.ws,
+                         keep=(self.keep[0:1], self.keep[1:2]))
+        d = run.head.dlogits
+        if self.world > 1:
+            d.mul_(1.0 / self.world)            # sum over ranks of per-rank means -> global mean
+        model._backward(run, d, self.grads, self.ws)
+        if self.world > 1:
+            self._allreduce()
+        if run.l2:
+            ops.l2_grad_add(self.g, self.arena.flat, self.arena.tnorm, L2_LAMBDA, self.arena.table)
+        self._update()
+        self.loss = run.loss
+        self.logits = run.head.logits
+        self.probs = run.head.probs
+
+    def _allreduce(self):
+        for lo, hi in self._buckets:
+            torch.distributed.all_reduce(self.g[lo:hi], group=self.pg)
+
+    def _update(self):
+        do_clip = self.max_norm is not None
+        if do_clip:
+            ops.grad_norm(self.g, self.arena.table, self.state)
+        ops.adamw_step(self.arena.flat, self.g, self.m, self.v, self.state, self.lr, self.betas[0], self.betas[1],
+                       self.eps, self.wd, self.max_norm if do_clip else 0.0, do_clip)
+
+    # ------------------------------------------------------------------ public API
+    def step(self, audio=None, input_ids=None, labels=None, wave=None):
+        """Runs one optimisation step.  Returns the device tensor holding the loss (no host sync)."""
+        model = self.model
+        if labels is None:
+            raise ValueError("labels are required for a training step")
+        if wave is not None and self.frontend is None:
+            raise ValueError("pass frontend=LogMelFrontEnd(...) to train from waveforms")
+        if not model.training:
+            raise RuntimeError("TrainStep.step() needs model.train()")
+        if model.modality == "both":
+            da, dt = model.fusion_layer.draw_modality_dropout()     # host RNG, audio first, as the reference
+            self.keep.copy_(self._keep_table[int(da) + 2 * int(dt)])
+        dev = self.arena.device
+        if wave is not None:
+            audio = None
+        ins = {"audio": audio, "input_ids": input_ids, "labels": labels, "wave": wave}
+        if model.modality == "text":
+            ins["audio"] = ins["wave"] = None
+        if model.modality == "audio":
+            ins["input_ids"] = None
+        model._check_inputs(ins["audio"] if ins["wave"] is None else ins["wave"], ins["input_ids"])
+        for k, t in ins.items():
+            if t is not None:
+                want = torch.int64 if k in ("input_ids", "labels") else torch.float32
+                ins[k] = t.to(device=dev, dtype=want, non_blocking=True).contiguous()
+        if not self.use_graph or self.world > 1:
+            self._body(ins["audio"], ins["input_ids"], ins["labels"], ins["wave"])
+            return self.loss
+        # graph mode: inputs are copied into static buffers, the captured launch sequence is replayed
+        for k, t in ins.items():
+            if t is None:
+                continue
+            s = self._static.get(k)
+            if s is None or s.shape != t.shape:
+                if self._graph is not None:
+                    raise ValueError("graph mode needs fixed input shapes (the reference's loader uses drop_last)")
+                self._static[k] = t.clone()
+            else:
+                s.copy_(t)
+        st = self._static
+        args = (st.get("audio"), st.get("input_ids"), st.get("labels"), st.get("wave"))
+        if self._graph is None:
+            if self._warm < 2:                 # eager warm-up: sizes every workspace buffer before capture
+                self._warm += 1
+                self._body(*args)
+                return self.loss
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body(*args)
+            self._graph = g                    # capture only records: the replay below executes this step
+        self._graph.replay()
+        return self.loss
+
+    @torch.no_grad()
+    def grad_norm(self) -> torch.Tensor:
+        return self.state[4]
+
+    def state_dict(self):
+        """Optimiser state in ``torch.optim.AdamW.state_dict()`` layout (multimodal_train.py:347 saves that)."""
+        step = float(self.state[0].item())
+        ms, vs = self.arena.views_of(self.m), self.arena.views_of(self.v)
+        state = {i: {"step": torch.tensor(step), "exp_avg": ms[i].clone(), "exp_avg_sq": vs[i].clone()}
+                 for i in range(len(ms))} if step > 0 else {}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                 "differentiable": False, "fused": None, "params": list(range(len(ms)))}
+        return {"state": state, "param_groups": [group]}
