@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train utterances/sec, CNN --modality both, batch 32 per GPU, fp32.
+
+One step = log-mel front end on 32 resident waveforms -> forward -> backward -> (gradient all-reduce over RCCL
+when N > 1) -> L2 term -> global-norm clip -> AdamW, i.e. `CNN implementation/multimodal_train.py:175-202` plus
+the mel stage of `preprocess.py:151-168`, all in hand-written HIP kernels.  Inputs are synthetic and already in
+HBM when the timed region starts.  Rank 0 prints ONE JSON line.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "multimodal-sentiment-analysis_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PER_GPU_BATCH = 32
+FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X dense fp32 MFMA peak
+HBM_PEAK_GBS = 8000.0
+TRAIN_FLOP_PER_UTT = 2_430_343_296   # forward 811.7 MFLOP x 3 minus the stem's unused data gradient
+N_DISTINCT_BATCHES = 4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5, help="instrumented steps for the per-kernel roofline")
+    return ap.parse_args()
+
+
+def cpu_baseline(budget_s=12.0):
+    """Oracle (CPU restatement of the reference) on the host cores: same step, same synthetic batch shape."""
+    from mmsa_amd import data
+    from mmsa_amd.model import MultimodalSentimentModel
+    from oracle import frontend_ref, train_ref
+    torch.manual_seed(42)
+    m = MultimodalSentimentModel("both", audio_dropout=0.0, text_dropout=0.0, fusion_dropout=0.0)
+    st = train_ref.TrainState(m.state_dict(), "both")
+    cores = torch.get_num_threads()
+    b = data.make_batch(0, PER_GPU_BATCH, with_wave=True)
+    wave = torch.from_numpy(b["wave"])
+    ids, lab = torch.from_numpy(b["input_ids"]), torch.from_numpy(b["label"])
+    spec = frontend_ref.logmel_f32(wave)
+    st.step(spec, ids, lab)                      # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        spec = frontend_ref.logmel_f32(wave)
+        st.step(spec, ids, lab)
+        n += 1
+        el = time.perf_counter() - t0
+        if (el > budget_s and n >= 3) or n >= 200:
+            break
+    return {"value": round(n * PER_GPU_BATCH / el, 2), "unit": "utt/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of batch {PER_GPU_BATCH} (front end + fwd + bwd + clip + AdamW) in {el:.1f} s, "
+                      f"torch CPU fp32, {cores} threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus > 1 launch with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=dev)
+
+    from mmsa_amd import data, ops
+    from mmsa_amd.frontend import LogMelFrontEnd
+    from mmsa_amd.model import MultimodalSentimentModel
+    from mmsa_amd.trainer import TrainStep
+
+    torch.manual_seed(42)
+    model = MultimodalSentimentModel("both", audio_dropout=0.0, text_dropout=0.0, fusion_dropout=0.0).to(dev).train()
+    fe = LogMelFrontEnd(dev)
+    use_graph = (not args.no_graph) and world == 1
+    ts = TrainStep(model, lr=1e-3, weight_decay=1e-4, max_norm=1.0, frontend=fe, use_graph=use_graph)
+
+    batches = []
+    for i in range(N_DISTINCT_BATCHES):
+        start = (i * world + rank) * PER_GPU_BATCH           # each rank gets its own shard of utterances
+        b = data.make_batch(start, PER_GPU_BATCH, with_wave=True)
+        batches.append({k: torch.from_numpy(b[k]).to(dev) for k in ("wave", "input_ids", "label")})
+
+    def run(i):
+        b = batches[i % N_DISTINCT_BATCHES]
+        return ts.step(wave=b["wave"], input_ids=b["input_ids"], labels=b["label"])
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(max(args.warmup, 3 if use_graph else 1)):
+        run(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = run(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss)
+    if not (final_loss == final_loss) or abs(final_loss) > 1e4:
+        raise SystemExit(f"training diverged: loss {final_loss}")
+
+    roofline = None
+    if rank == 0:
+        # per-kernel timing of the dense contractions with HIP events on the launch stream (instrumented eager steps)
+        ops.PROFILE = {}
+        ts_prof = ts if not use_graph else TrainStep(model, frontend=fe, use_graph=False)
+        for i in range(args.profile_steps):
+            b = batches[i % N_DISTINCT_BATCHES]
+            ts_prof.step(wave=b["wave"], input_ids=b["input_ids"], labels=b["label"])
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        agg = {}
+        for kind, recs in prof.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            agg[kind] = (ms, fl, len(recs))
+        if agg:
+            kind = max(agg, key=lambda k: agg[k][0])
+            ms, fl, cnt = agg[kind]
+            ach = fl / (ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": kind, "achieved": round(ach, 2), "peak": FP32_MATRIX_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                        "launches": cnt, "avg_launch_us": round(ms * 1e3 / cnt, 2),
+                        "all_kernels": {k: {"ms_per_step": round(v[0] / args.profile_steps, 4),
+                                            "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else None}
+                                        for k, v in agg.items()}}
+    elif world > 1 and False:
+        pass
+
+    if rank == 0:
+        utt = world * PER_GPU_BATCH * args.steps
+        value = utt / elapsed
+        out = {
+            "metric": "train utterances/sec, CNN --modality both", "value": round(value, 1), "unit": "utt/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "CNN --modality both train step (log-mel front end + fwd + bwd + L2 term + clip 1.0 "
+                                   "+ AdamW lr 1e-3 wd 1e-4), batch 32/GPU, 3 s @ 22.05 kHz waveforms, 128 tokens, "
+                                   "vocab 30522, dropout 0", "global_batch": world * PER_GPU_BATCH,
+                       "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}",
+                       "launch": "hip-graph replay" if use_graph else "eager"},
+            "model_tflops": round(value * TRAIN_FLOP_PER_UTT / 1e12, 2),
+            "model_frac_of_fp32_matrix_peak": round(value * TRAIN_FLOP_PER_UTT / 1e12 / (world * FP32_MATRIX_PEAK_TFLOPS), 4),
+            "final_loss": round(final_loss, 5),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void dense_bwd_x_kernel(const float* __restric
   for (int n = t; n < N; n += 256) {
     float d = dY[(long)b * ldy + n];
     if (drop_p > 0.f) d = hash_uniform(seed, (unsigned long long)b * N + n) >= drop_p ? d * keep_scale : 0.f;
-    const float p = pre[(long)b * N + n];
+    const float p = epi == EPI_NONE ? 0.f : pre[(long)b * N + n];   // pre is null for plain linear layers
     if (epi == EPI_LN_RELU) {
       const float xh = (p - mean) * rstd;
       if (fmaf(xh, gamma[n], beta[n]) <= 0.f) d = 0.f;

@@ -20,6 +20,20 @@ TAPS3X3 = [(dh, dw) for dh in (-1, 0, 1) for dw in (-1, 0, 1)]   # kernel index 
 TAPS1X1 = [(0, 0)]
 
 
+# When set to a dict, the dense-contraction wrappers bracket each launch with HIP events on the launch stream:
+# {kernel instantiation name: [(start_event, end_event, algorithmic_flops), ...]} (used by bench.py only).
+PROFILE = None
+
+
+def _prof_begin(kind: str, flops: float):
+    if PROFILE is None:
+        return None
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    PROFILE.setdefault(kind, []).append((s, e, flops))
+    s.record()
+    return e
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -93,8 +107,16 @@ def conv_fwd(X, Wp, Y, stats, B, H, W, Cin, Cout, taps, negate=False, accumulate
         if stats.numel() != rows * 2 * Cout:
             raise ValueError("conv_fwd: stats buffer has the wrong size")
     sgn = -1 if negate else 1
+    ev = None
+    if PROFILE is not None:
+        bm, bn = (128, 32) if Cout % 64 else (conv_tile_rows(B, H, W, Cout), 64)
+        kind = "conv_igemm_kernel<%d,%d,%s,%s>" % (bm, bn, "stats" if stats is not None else "nostats",
+                                                    "accum" if accumulate else "store")
+        ev = _prof_begin(kind, 2.0 * B * H * W * Cin * Cout * len(taps))
     _lib.call("mmsa_conv_fwd", _chk(X), _chk(Wp), _chk(Y), _opt(stats), B, H, W, Cin, Cout, len(taps),
               _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), int(accumulate), _stream())
+    if ev is not None:
+        ev.record()
 
 
 def conv_wgrad_workspace(B, H, W, Cin, Cout, ntaps) -> int:
@@ -106,9 +128,12 @@ def conv_wgrad(X, dY, dW, workspace, B, H, W, Cin, Cout, taps, w_valid=None, acc
         raise ValueError("conv_wgrad: operand sizes do not match the geometry")
     if workspace.numel() < conv_wgrad_workspace(B, H, W, Cin, Cout, len(taps)):
         raise ValueError("conv_wgrad: workspace too small")
+    ev = _prof_begin("conv_wgrad_kernel<%d>" % len(taps), 2.0 * B * H * W * Cin * Cout * len(taps))
     _lib.call("mmsa_conv_wgrad", _chk(X), _chk(dY), _chk(dW), _chk(workspace), B, H, W,
               W if w_valid is None else w_valid, Cin, Cout, len(taps), _iarr([t[0] for t in taps]),
               _iarr([t[1] for t in taps]), int(accumulate), _stream())
+    if ev is not None:
+        ev.record()
 
 
 # ---------------------------------------------------------------------------------------------- audio branch

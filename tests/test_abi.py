@@ -1,0 +1,78 @@
+"""CPU tests of the drop-in boundary: the shared library loads and exports every symbol include/mmsa.h declares,
+argument checks reject bad shapes without launching anything, and host-only helpers work without a GPU."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from mmsa_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build the library first: python -m mmsa_amd.build"
+    protos = _lib.parse_header(os.path.join(ROOT, "include", "mmsa.h"))
+    assert len(protos) >= 35
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in protos if not hasattr(lib, n)]
+    assert not missing, missing
+    _lib.load()
+    # nothing but the declared C ABI is exported with the mmsa_ prefix
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line and "mmsa_" in line}
+    assert exported == set(protos), exported ^ set(protos)
+
+
+def test_host_table_helper_and_geometry_queries():
+    from mmsa_amd import _lib
+    win = np.zeros(1024, np.float32)
+    t5 = np.zeros(512, np.float32)
+    t10 = np.zeros(1026, np.float32)
+    _lib.call("mmsa_logmel_tables_host", win.ctypes.data_as(ctypes.c_void_p), t5.ctypes.data_as(ctypes.c_void_p),
+              t10.ctypes.data_as(ctypes.c_void_p))
+    n = np.arange(1024)
+    np.testing.assert_allclose(win, 0.5 - 0.5 * np.cos(2 * np.pi * n / 1024), atol=1e-7)
+    assert t5[0] == 1.0 and abs(t5[2 * 128] - 0.0) < 1e-7 and abs(t5[2 * 128 + 1] + 1.0) < 1e-7
+    assert abs(t10[2 * 512] + 1.0) < 1e-7
+    assert _lib.query("mmsa_conv_tile_rows", 32, 32, 65, 64) in (64, 128)
+    assert _lib.query("mmsa_conv_wgrad_workspace_floats", 32, 32, 65, 64, 64, 9, None) > 0
+    assert _lib.query("mmsa_resblock_bwd_scratch_floats", 32, 32, 65, 64) > 0
+    with pytest.raises(_lib.MmsaError):
+        _lib.query("mmsa_resblock_bwd_scratch_floats", 32, 32, 65, 48)      # channels must be 64/128/256
+
+
+def test_bad_arguments_are_rejected_before_any_launch():
+    from mmsa_amd import _lib
+    lib = _lib.load()
+    # null pointers / bad geometry -> MMSA_ERR_ARG (-1), nothing touches the (absent) GPU
+    assert lib.mmsa_conv_fwd(None, None, None, None, 1, 1, 1, 32, 64, 9, None, None, 0, None) == -1
+    assert lib.mmsa_embedding_gather(None, None, None, 4, 256, 1000, None, None) == -1
+    assert lib.mmsa_adamw_step(None, None, None, None, 8, None, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1.0, 1, None) == -1
+    with pytest.raises(_lib.MmsaError):
+        _lib.call("mmsa_softmax_ce", None, None, None, None, None, 4, 3, None)
+
+
+def test_mel_filterbank_shape_and_support():
+    from mmsa_amd.frontend import htk_mel_filterbank
+    from oracle import frontend_ref
+    fb = htk_mel_filterbank()
+    assert fb.shape == (513, 64)
+    assert int((fb > 0).sum()) == 998                       # non-zeros of the 64 HTK triangles at n_fft 1024
+    assert (fb.sum(0) > 0).all()                            # no empty filter
+    assert np.array_equal(fb.numpy(), frontend_ref.mel_filterbank().numpy())
+
+
+def test_synthetic_data_is_deterministic_and_well_formed():
+    from mmsa_amd import data
+    a, b = data.make_batch(7, 5, with_wave=True), data.make_batch(7, 5, with_wave=True)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    assert a["audio"].shape == (5, 1, 64, 130) and a["wave"].shape == (5, 66150)
+    ids = a["input_ids"]
+    assert ids.dtype == np.int64 and (ids[:, 0] == 101).all() and ((ids == 102).sum(1) == 1).all()
+    assert np.array_equal(a["attention_mask"], (ids != 0).astype(np.int64))
+    assert set(np.unique(data.label_batch(0, 200))) == {0, 1, 2}
+    rows = data.csv_rows(0, 3)
+    assert rows[0] == "Audio_ID;Sentiment;Utterance" and rows[1].split(";")[1] in data.SENTIMENTS

@@ -1,0 +1,195 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (mmsa_amd.ops -> libmmsa_hip.so).
+
+Checker: torch fp32/fp64 CPU arithmetic and the oracle under oracle/.  Tolerances are stated per test;
+index/byte work (gather, argmax) must be bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import batch_tensors
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from mmsa_amd import ops
+    return ops
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def check(a, b, tol):
+    e = rel_err(a, b)
+    assert e < tol, f"relative error {e:.3e} exceeds {tol:.1e}"
+
+
+# ------------------------------------------------------------------------------------------------ front end
+def test_logmel_matches_oracle():
+    from mmsa_amd import data
+    from mmsa_amd.frontend import LogMelFrontEnd
+    from oracle import frontend_ref
+    wave = torch.from_numpy(data.waveform_batch(0, 6))
+    fe = LogMelFrontEnd(DEV)
+    got = fe(wave.to(DEV)).cpu()
+    assert got.shape == (6, 1, 64, 130)
+    ref64 = torch.from_numpy(frontend_ref.logmel_f64(wave.numpy()))
+    ref32 = frontend_ref.logmel_f32(wave)
+    # mel features within 1e-4 relative (of the map's dynamic range; values are z-scores clamped to +-6)
+    check(got, ref64, 1e-4)
+    check(got, ref32, 2e-4)
+    assert abs(float(got.mean())) < 1e-3 and abs(float(got.std()) - 1.0) < 0.05
+
+
+def test_logmel_edge_cases():
+    """Short input is zero-padded, long input trimmed, silence gives zeros (std 0 -> 0/1e-8), strided rows work."""
+    from mmsa_amd.frontend import LogMelFrontEnd
+    from oracle import frontend_ref
+    fe = LogMelFrontEnd(DEV)
+    g = torch.Generator().manual_seed(3)
+    short = torch.randn(2, 30000, generator=g) * 0.1
+    long = torch.randn(2, 90000, generator=g) * 0.1
+    for w in (short, long):
+        got = fe(w.to(DEV)).cpu()
+        ref = torch.from_numpy(frontend_ref.logmel_f64(w.numpy()))
+        check(got, ref, 1e-4)
+    sil = fe(torch.zeros(1, 66150, device=DEV)).cpu()
+    assert torch.equal(sil, torch.zeros_like(sil))
+    base = torch.randn(3, 70000, generator=g) * 0.05
+    view = base.to(DEV)[:, :66150]          # row stride 70000
+    got = fe(view).cpu()
+    ref = torch.from_numpy(frontend_ref.logmel_f64(base[:, :66150].numpy()))
+    check(got, ref, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ gather
+def test_embedding_gather_bit_exact():
+    ops = _ops()
+    g = torch.Generator().manual_seed(0)
+    table = torch.randn(30522, 256, generator=g)
+    ids = torch.randint(0, 30522, (5, 128), generator=g)
+    ids[0, :4] = torch.tensor([0, 101, 102, 30521])
+    out = torch.empty(5, 128, 256, device=DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.embedding_gather(ids.to(DEV), table.to(DEV), out, err)
+    assert torch.equal(out.cpu(), table[ids])
+    assert int(err.item()) == 0
+    bad = ids.clone()
+    bad[1, 1] = 30522
+    ops.embedding_gather(bad.to(DEV), table.to(DEV), out, err)
+    assert int(err.item()) == 1 and torch.equal(out[1, 1].cpu(), torch.zeros(256))
+
+
+# ------------------------------------------------------------------------------------------------ convolutions
+GEOMS = [(3, 32, 65, 32, 64), (3, 32, 65, 64, 64), (2, 16, 32, 64, 128), (2, 16, 32, 128, 128),
+         (2, 8, 16, 128, 256), (2, 8, 16, 256, 256), (32, 8, 16, 128, 256), (40, 16, 32, 64, 128)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", GEOMS)
+def test_conv3x3_forward_and_stats(B, H, W, Cin, Cout):
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cout)) ** 0.5
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    wf = torch.empty(w.numel(), device=DEV)
+    ops.pack_weights(w.to(DEV), wf, None)
+    y = torch.empty(B, H, W, Cout, device=DEV)
+    rows, tiles = ops.conv_stats_rows(B, H, W, Cout)
+    stats = torch.zeros(rows, 2, Cout, device=DEV)
+    ops.conv_fwd(nhwc(x).to(DEV), wf, y, stats, B, H, W, Cin, Cout, ops.TAPS3X3)
+    check(nchw(y.cpu()), ref, 5e-6)
+    s = stats.cpu().double()
+    refn = nhwc(ref)
+    np.testing.assert_allclose(s[:, 0].sum(0).numpy(), refn.sum((0, 1, 2)).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s[:, 1].sum(0).numpy(), (refn ** 2).sum((0, 1, 2)).numpy(), rtol=1e-4, atol=1e-3)
+    per_img = s[:, 0].view(B, tiles, Cout).sum(1)
+    np.testing.assert_allclose(per_img.numpy(), refn.sum((1, 2)).numpy(), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 32, 65, 32, 64), (2, 16, 32, 64, 128), (2, 8, 16, 128, 256)])
+def test_conv1x1_and_dgrad(B, H, W, Cin, Cout):
+    ops = _ops()
+    g = torch.Generator().manual_seed(7 + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w3 = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    w1 = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    # 1x1 forward
+    wf1, wd1 = torch.empty(w1.numel(), device=DEV), torch.empty(w1.numel(), device=DEV)
+    ops.pack_weights(w1.to(DEV), wf1, wd1)
+    y = torch.empty(B, H, W, Cout, device=DEV)
+    ops.conv_fwd(nhwc(x).to(DEV), wf1, y, None, B, H, W, Cin, Cout, ops.TAPS1X1)
+    check(nchw(y.cpu()), F.conv2d(x.double(), w1.double()), 2e-6)
+    # data gradients: 3x3 then accumulate the 1x1 on top (what a residual block's backward does)
+    wf3, wd3 = torch.empty(w3.numel(), device=DEV), torch.empty(w3.numel(), device=DEV)
+    ops.pack_weights(w3.to(DEV), wf3, wd3)
+    dx = torch.empty(B, H, W, Cin, device=DEV)
+    dyd = nhwc(dy).to(DEV)
+    ops.conv_fwd(dyd, wd3, dx, None, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
+    xr = x.double().requires_grad_(True)
+    F.conv2d(xr, w3.double(), None, 1, 1).backward(dy.double())
+    ref3 = xr.grad.clone()
+    check(nchw(dx.cpu()), ref3, 2e-6)
+    ops.conv_fwd(dyd, wd1, dx, None, B, H, W, Cout, Cin, ops.TAPS1X1, negate=True, accumulate=True)
+    xr.grad = None
+    F.conv2d(xr, w1.double()).backward(dy.double())
+    check(nchw(dx.cpu()), ref3 + xr.grad, 2e-6)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 32, 65, 32, 64), (3, 32, 65, 64, 64), (2, 16, 32, 64, 128),
+                                            (2, 8, 16, 256, 256), (32, 8, 16, 128, 256)])
+def test_conv_wgrad(B, H, W, Cin, Cout):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    for taps, k, pad in ((ops.TAPS3X3, 3, 1), (ops.TAPS1X1, 1, 0)):
+        w = torch.zeros(Cout, Cin, k, k, dtype=torch.double, requires_grad=True)
+        F.conv2d(x.double(), w, None, 1, pad).backward(dy.double())
+        dW = torch.empty(Cout, Cin, k, k, device=DEV)
+        wsz = ops.conv_wgrad_workspace(B, H, W, Cin, Cout, len(taps))
+        wk = torch.empty(wsz, device=DEV)
+        ops.conv_wgrad(nhwc(x).to(DEV), nhwc(dy).to(DEV), dW, wk, B, H, W, Cin, Cout, taps)
+        check(dW.cpu(), w.grad, 5e-6)
+        ops.conv_wgrad(nhwc(x).to(DEV), nhwc(dy).to(DEV), dW, wk, B, H, W, Cin, Cout, taps, accumulate=True)
+        check(dW.cpu(), 2 * w.grad, 5e-6)
+
+
+def test_text_conv_relu_maxtime():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    B, L, E, Fn = 5, 128, 256, 128
+    emb = torch.randn(B, L, E, generator=g)
+    feat = torch.zeros(B, 3 * Fn, device=DEV)
+    arg = torch.zeros(B, 3 * Fn, dtype=torch.int32, device=DEV)
+    refs, args = [], []
+    for i, k in enumerate((3, 4, 5)):
+        w = torch.randn(Fn, E, k, generator=g) * 0.05
+        bias = torch.randn(Fn, generator=g) * 0.1
+        wp = torch.empty(w.numel(), device=DEV)
+        ops.pack_weights(w.to(DEV), wp, None)
+        y = torch.empty(B, L, Fn, device=DEV)
+        ops.conv_fwd(emb.to(DEV), wp, y, None, B, 1, L, E, Fn, [(0, j) for j in range(k)])
+        ops.bias_relu_maxtime(y, bias.to(DEV), feat, arg, B, L, L - k + 1, Fn, 3 * Fn, i * Fn)
+        c = F.relu(F.conv1d(emb.double().transpose(1, 2), w.double(), bias.double()))
+        m, a = c.max(dim=2)
+        refs.append(m)
+        args.append(a)
+    ref = torch.cat(refs, 1)
+    check(feat.cpu(), ref, 2e-6)
+    ra = torch.cat(args, 1)
+    pos = ref > 1e-4          # where the max is a clear positive, the arg-max index must agree exactly
+    assert torch.equal(arg.cpu().long()[pos], ra[pos])
