@@ -152,12 +152,15 @@ MMSA_API int mmsa_param_norms(const float* p, const long long* chunk_off, const 
                               float* sum_out, void* stream);
 MMSA_API int mmsa_l2_grad_add(float* g, const float* p, const float* tnorm, float lambda, const long long* chunk_off,
                               const int* chunk_len, const int* chunk_tensor, int nchunks, void* stream);
-MMSA_API int mmsa_grad_norm(const float* g, const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
-                            int nchunks, const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* state,
-                            void* stream);
+/* state[4] = global norm of g (+ lambda * p / ||p|| per tensor when p and tnorm are given) */
+MMSA_API int mmsa_grad_norm(const float* g, const float* p, const float* tnorm, float lambda,
+                            const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,
+                            const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* state, void* stream);
 /* state (8 floats): 0 step, 1 1-beta1^t, 2 sqrt(1-beta2^t), 3 clip coefficient, 4 total grad norm, 5 sum of norms */
-MMSA_API int mmsa_adamw_step(float* p, const float* g, float* m, float* v, long n, float* state, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, float max_norm, int do_clip, void* stream);
+MMSA_API int mmsa_adamw_step(float* p, const float* g, float* m, float* v, const long long* chunk_off,
+                             const int* chunk_len, const int* chunk_tensor, int nchunks, const float* tnorm,
+                             float lambda, float* state, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, float max_norm, int do_clip, void* stream);
 MMSA_API int mmsa_scale_by_state(float* g, long n, const float* state, int idx, void* stream);
 MMSA_API int mmsa_scalar_axpy(float* dst, const float* a, const float* b, float alpha, void* stream);
 

@@ -217,18 +217,29 @@ __global__ __launch_bounds__(256) void stem_bwd_w_kernel(const float* __restrict
   }
 }
 
-// sum partial[rows][320] (c*10+k) -> dW[32*9], dbias[32]
-__global__ __launch_bounds__(256) void stem_bwd_w_finalize_kernel(const float* __restrict__ partial, int rows,
-                                                                  float* __restrict__ dW, float* __restrict__ db) {
-  __shared__ double red[4][64];
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
-  double s = 0.0;
-  if (col < 320)
-    for (int r = w; r < rows; r += 4) s += (double)partial[(long)r * 320 + col];
-  red[w][threadIdx.x & 63] = s;
+// sum partial[rows][320] (c*10+k) -> dW[32*9], dbias[32].  64 columns per block, 16 waves split the rows.
+__global__ __launch_bounds__(1024) void stem_bwd_w_finalize_kernel(const float* __restrict__ partial, int rows,
+                                                                   float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ double red[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (col < 320) {
+    int r = w;
+    for (; r + 48 < rows; r += 64) {
+      s0 += (double)partial[(long)r * 320 + col];
+      s1 += (double)partial[(long)(r + 16) * 320 + col];
+      s2 += (double)partial[(long)(r + 32) * 320 + col];
+      s3 += (double)partial[(long)(r + 48) * 320 + col];
+    }
+    for (; r < rows; r += 16) s0 += (double)partial[(long)r * 320 + col];
+  }
+  red[w][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (w == 0 && col < 320) {
-    const double t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
     const int c = col / 10, k = col - c * 10;
     if (k < 9) dW[c * 9 + k] = (float)t; else db[c] = (float)t;
   }
@@ -236,34 +247,31 @@ __global__ __launch_bounds__(256) void stem_bwd_w_finalize_kernel(const float* _
 
 // ------------------------------------------------------------------------------------------------ BatchNorm
 // partial: [rows][2][C] sums / sums of squares (rows = B * tiles, tiles of one image contiguous).
-// One block per 64 channels; lane = channel (coalesced), the 4 waves split the rows, double accumulation.
+// One wave per channel: the 64 lanes stride over the rows (independent loads), double accumulation, wave reduce.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int tiles_per_img,
                                                           double count, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ rmean,
                                                           float* __restrict__ rvar, long long* __restrict__ nbt,
                                                           float momentum, float eps, int training,
                                                           float* __restrict__ coeff, float* __restrict__ bsum, int C) {
-  __shared__ double red[2][4][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  const bool cv = c < C;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+  if (c >= C) return;   // whole wave
   double s = 0.0, q = 0.0;
-  if (cv && training) {
-    for (int r = w; r < rows; r += 4) {
+  if (training) {
+    for (int r = lane; r < rows; r += 64) {
       s += (double)partial[((long)r * 2) * C + c];
       q += (double)partial[((long)r * 2 + 1) * C + c];
     }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
   }
-  red[0][w][lane] = s;
-  red[1][w][lane] = q;
-  __syncthreads();
-  if (w == 0 && cv) {
+  if (lane == 0) {
     float mean, var;
     if (training) {
-      const double ts = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-      const double tq = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
-      const double m = ts / count;
-      double v = tq / count - m * m;
+      const double m = s / count;
+      double v = q / count - m * m;
       if (v < 0.0) v = 0.0;
       mean = (float)m;
       var = (float)v;
@@ -283,10 +291,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     coeff[2 * C + c] = sc;
     coeff[3 * C + c] = beta[c] - mean * sc;
   }
-  if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
-  if (bsum && cv) {
+  if (bsum) {
     const int B = rows / tiles_per_img;
-    for (int b = w; b < B; b += 4) {
+    for (int b = lane; b < B; b += 64) {
       float t = 0.f;
       for (int i = 0; i < tiles_per_img; ++i) t += partial[(((long)b * tiles_per_img + i) * 2) * C + c];
       bsum[(long)b * C + c] = t;
@@ -649,27 +656,21 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_stats_kernel(const float* __r
 }
 
 // sums the partial rows, writes dgamma/dbeta, s12 = [S1[C], S2[C]] and cb[3][C] = (scale, Q, R) with
-// d_x = [relu mask]*scale*dy + Q*x + R
+// d_x = [relu mask]*scale*dy + Q*x + R.  One wave per channel, lanes stride over the rows.
 __global__ __launch_bounds__(256) void bn_bwd_coeff_kernel(const float* __restrict__ partial, int rows, double count,
                                                            const float* __restrict__ coeff, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, float* __restrict__ s12,
                                                            float* __restrict__ cb, int C, int training) {
-  __shared__ double red[2][4][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  const bool cv = c < C;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
   double s = 0.0, q = 0.0;
-  if (cv)
-    for (int r = w; r < rows; r += 4) {
-      s += (double)partial[((long)r * 2) * C + c];
-      q += (double)partial[((long)r * 2 + 1) * C + c];
-    }
-  red[0][w][lane] = s;
-  red[1][w][lane] = q;
-  __syncthreads();
-  if (w == 0 && cv) {
-    const double S1 = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
-    const double S2 = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+  for (int r = lane; r < rows; r += 64) {
+    s += (double)partial[((long)r * 2) * C + c];
+    q += (double)partial[((long)r * 2 + 1) * C + c];
+  }
+  const double S1 = wave_sum_d(s), S2 = wave_sum_d(q);
+  if (lane == 0) {
     if (dgamma) dgamma[c] = (float)S2;
     if (dbeta) dbeta[c] = (float)S1;
     if (s12) { s12[c] = (float)S1; s12[C + c] = (float)S2; }
@@ -747,12 +748,12 @@ MMSA_EXPORT int mmsa_stem_bwd(const float* x, const float* w, const float* bias,
   float* p2 = s12 + 64;                   // [rows][320]
   const size_t sh1 = (4 * (W + 2) + 8 * 2 * 32) * sizeof(float);
   hipLaunchKernelGGL(stem_bwd_stats_kernel, dim3(rows), dim3(256), sh1, s, x, w, bias, coeff, dout, p1, H, W);
-  hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(1), dim3(256), 0, s, p1, rows, (double)B * H * W, coeff, dgamma, dbeta,
+  hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(8), dim3(256), 0, s, p1, rows, (double)B * H * W, coeff, dgamma, dbeta,
                      s12, (float*)nullptr, 32, training);
   const size_t sh2 = (4 * (W + 2) + 8 * 320) * sizeof(float);
   const float inv_n = training ? 1.0f / ((float)B * H * W) : 0.f;
   hipLaunchKernelGGL(stem_bwd_w_kernel, dim3(rows), dim3(256), sh2, s, x, w, bias, coeff, dout, s12, inv_n, p2, H, W);
-  hipLaunchKernelGGL(stem_bwd_w_finalize_kernel, dim3(5), dim3(256), 0, s, p2, rows, dW, dbias);
+  hipLaunchKernelGGL(stem_bwd_w_finalize_kernel, dim3(5), dim3(1024), 0, s, p2, rows, dW, dbias);
   return mmsa_launch_status();
 }
 
@@ -765,7 +766,7 @@ MMSA_EXPORT int mmsa_bn_finalize(const float* partial, int rows, int tiles_per_i
   MMSA_REQUIRE(gamma && beta && coeff && C > 0 && rows >= 0 && tiles_per_img > 0);
   MMSA_REQUIRE(training ? (partial && count > 0) : (running_mean && running_var));
   MMSA_REQUIRE(!bsum || (partial && rows % tiles_per_img == 0));
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(mmsa_cdiv(C, 64)), dim3(256), 0, mmsa_stream(stream), partial, rows,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(mmsa_cdiv(C, 4)), dim3(256), 0, mmsa_stream(stream), partial, rows,
                      tiles_per_img, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, training, coeff,
                      bsum, C);
   return mmsa_launch_status();
@@ -882,7 +883,7 @@ MMSA_EXPORT int mmsa_bn_relu_bwd(float* dh, const float* c1, const float* coeff,
   const int planes = 1024 / C;
   hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, dim3(blocks), dim3(256), (size_t)planes * 2 * C * sizeof(float), s, dh,
                      c1, coeff, partial, npos, C, pos_per_block);
-  hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(mmsa_cdiv(C, 64)), dim3(256), 0, s, partial, blocks, (double)npos, coeff,
+  hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(mmsa_cdiv(C, 4)), dim3(256), 0, s, partial, blocks, (double)npos, coeff,
                      dgamma, dbeta, (float*)nullptr, cb, C, training);
   const long n4 = npos * (C / 4);
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dh, c1, coeff, cb, n4, C);

@@ -211,97 +211,154 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// Weight gradient.  grid = (tile pairs (cin32 x cout32), nsplit).  Rows (b,h) of the image are dealt to
-// (split, wave) round-robin.  partial[split][tap][Cin][Cout].
+// Weight gradient.  grid = (cin tiles of 32 x cout groups of 64, nsplit).  A workgroup walks over strips of R
+// image rows (strip = blockIdx.y, += gridDim.y); per strip it stages the X rows r0-1 .. r0+R with a zero halo
+// column on each side ([R+2][W+2][32 cin]) and the dY rows ([R][W][64 cout]) in LDS, so the inner loop has no
+// bounds checks: every MFMA operand is one conflict-free ds_read_b32 (32 consecutive channels per lane half).
+// Waves: (cout tile of 32) x (tap group: taps 0..4 / 5..8) for 3x3; for 1x1 the second index splits the rows
+// instead and each half writes its own slab.  Accumulators stay in registers across strips; each workgroup
+// writes one partial slab [tap][Cin][Cout] (two for 1x1), summed in fixed order by wgrad_reduce_kernel.
 template <int NT>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
-                                                         float* __restrict__ partial, ConvGeom g, int w_valid) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                            float* __restrict__ partial, ConvGeom g, int R, int nstrips,
+                                                            int strips_per_img) {
+  constexpr int MAXT = NT == 1 ? 1 : (NT + 1) / 2;
   extern __shared__ float lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int WP = g.W + 2;
+  float* Xs = lds;
+  float* Ys = lds + (R + 2) * WP * 32;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 31, kk = lane >> 5;
-  const int cout_tiles = g.Cout / 32;
-  const int cin0 = (blockIdx.x / cout_tiles) * 32;
-  const int cout0 = (blockIdx.x % cout_tiles) * 32;
-  const int nsplit = gridDim.y;
-  const int rows = g.B * g.H;
+  const int jt = wave & 1, q = wave >> 1;
+  const int cgroups = g.Cout / 64;
+  const int cin0 = (blockIdx.x / cgroups) * 32;
+  const int cout0 = (blockIdx.x % cgroups) * 64;
+  const int t_first = NT == 1 ? 0 : (q == 0 ? 0 : MAXT);
+  const int t_count = NT == 1 ? 1 : (q == 0 ? MAXT : NT - MAXT);
+  int toff[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i) {
+    const int tap = min(t_first + i, NT - 1);
+    toff[i] = (g.dh[tap] * WP + g.dw[tap]) * 32;
+  }
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int i = 0; i < MAXT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  f32x16 acc[NT];
+  for (int strip = blockIdx.y; strip < nstrips; strip += gridDim.y) {
+    const int b = strip / strips_per_img;
+    const int r0 = (strip - b * strips_per_img) * R;
+    __syncthreads();  // the previous strip's reads are done
+    const float* Xb = X + (long)b * g.H * g.W * g.Cin + cin0;
+    for (int i = t; i < (R + 2) * WP * 8; i += 256) {
+      const int c4 = i & 7, pc = i >> 3;
+      const int row = pc / WP, col = pc - row * WP;
+      const int h = r0 - 1 + row, w = col - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (h >= 0 && h < g.H && w >= 0 && w < g.W)
+        v = *reinterpret_cast<const f32x4*>(Xb + ((long)h * g.W + w) * g.Cin + 4 * c4);
+      *reinterpret_cast<f32x4*>(Xs + (long)i * 4) = v;
+    }
+    const float* Yb = dY + (long)b * g.H * g.W * g.Cout + cout0;
+    for (int i = t; i < R * g.W * 16; i += 256) {
+      const int c4 = i & 15, pc = i >> 4;
+      const int row = pc / g.W, w = pc - row * g.W;
+      const int h = r0 + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (h < g.H) v = *reinterpret_cast<const f32x4*>(Yb + ((long)h * g.W + w) * g.Cout + 4 * c4);
+      *reinterpret_cast<f32x4*>(Ys + (long)i * 4) = v;
+    }
+    __syncthreads();
+    for (int r = (NT == 1 ? q : 0); r < R; r += (NT == 1 ? 2 : 1)) {
+      const float* yrow = Ys + (r * g.W) * 64 + jt * 32 + li;
+      const float* xrow = Xs + ((r + 1) * WP + 1) * 32 + li;
+      for (int w0 = 0; w0 < g.W; w0 += 2) {
+        const int w = w0 + kk;
+        const bool v = w < g.W;
+        const int wc = v ? w : g.W - 1;
+        const float dy = v ? yrow[wc * 64] : 0.f;
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  for (int row = blockIdx.y * 4 + wave; row < rows; row += nsplit * 4) {
-    const int b = row / g.H, h = row - b * g.H;
-    const float* dYr = dY + ((long)row * g.W) * g.Cout + cout0 + li;
-    const float* Xb = X + ((long)b * g.H * g.W) * g.Cin + cin0 + li;
-    for (int w0 = 0; w0 < w_valid; w0 += 2) {
-      const int w = w0 + kk;
-      const bool wv = w < w_valid;
-      const float dy = wv ? dYr[(long)w * g.Cout] : 0.f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int hh = h + g.dh[t], ww = w + g.dw[t];
-        float xv = 0.f;
-        if (wv && hh >= 0 && hh < g.H && ww >= 0 && ww < g.W) xv = Xb[((long)(hh * g.W + ww)) * g.Cin];
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv, dy, acc[t], 0, 0, 0);
+        for (int i = 0; i < MAXT; ++i)
+          if (i < t_count)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xrow[wc * 32 + toff[i]], dy, acc[i], 0, 0, 0);
       }
     }
   }
 
-  // combine the 4 waves: waves 2,3 -> LDS; waves 0,1 add; wave 1 -> LDS; wave 0 adds and writes.
-  float* bufA = lds;
-  float* bufB = lds + NT * 1024;
-  if (wave >= 2) {
-    float* dst = (wave == 2 ? bufA : bufB);
+  const int slab = NT == 1 ? (int)blockIdx.y * 2 + q : (int)blockIdx.y;
+  float* out = partial + (long)slab * NT * g.Cin * g.Cout;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[(t * 16 + r) * 64 + lane] = acc[t][r];
-  }
-  __syncthreads();
-  if (wave < 2) {
-    const float* src = (wave == 0 ? bufA : bufB);
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[t][r] += src[(t * 16 + r) * 64 + lane];
-  }
-  __syncthreads();
-  if (wave == 1) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) bufA[(t * 16 + r) * 64 + lane] = acc[t][r];
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float* out = partial + (long)blockIdx.y * NT * g.Cin * g.Cout;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
+  for (int i = 0; i < MAXT; ++i)
+    if (i < t_count) {
+      const int tap = t_first + i;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = acc[t][r] + bufA[(t * 16 + r) * 64 + lane];
-        const int ci = cin0 + (r & 3) + 8 * (r >> 2) + 4 * kk;   // D row
-        out[((long)t * g.Cin + ci) * g.Cout + cout0 + li] = v;   // D col = lane & 31
+        const int ci = cin0 + (r & 3) + 8 * (r >> 2) + 4 * kk;                          // D row
+        out[((long)tap * g.Cin + ci) * g.Cout + cout0 + jt * 32 + li] = acc[i][r];      // D col = lane & 31
       }
+    }
+}
+
+// partial[slab][tap][Cin][Cout] -> dW[Cout][Cin][ntaps]  (+= when accumulate).  64 outputs per workgroup, the
+// four waves take interleaved slabs (independent loads, unrolled) and are combined in fixed order through LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW,
+                                                           int nslabs, int ntaps, int Cin, int Cout, int accumulate) {
+  __shared__ float red[4][64];
+  const long total = (long)ntaps * Cin * Cout;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < total) {
+    int k = w;
+    for (; k + 12 < nslabs; k += 16) {
+      s0 += partial[(long)k * total + i];
+      s1 += partial[(long)(k + 4) * total + i];
+      s2 += partial[(long)(k + 8) * total + i];
+      s3 += partial[(long)(k + 12) * total + i];
+    }
+    for (; k < nslabs; k += 4) s0 += partial[(long)k * total + i];
+  }
+  red[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && i < total) {
+    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const int co = (int)(i % Cout);
+    const long r = i / Cout;
+    const int ci = (int)(r % Cin);
+    const int tp = (int)(r / Cin);
+    float* dst = dW + ((long)co * Cin + ci) * ntaps + tp;
+    *dst = accumulate ? (*dst + s) : s;
   }
 }
 
-// partial[split][tap][Cin][Cout] -> dW[Cout][Cin][ntaps]  (+= when accumulate)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW, int nsplit, int ntaps,
-                                    int Cin, int Cout, int accumulate) {
-  const long total = (long)ntaps * Cin * Cout;
-  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += partial[(long)k * total + i];
-  const int co = (int)(i % Cout);
-  const long r = i / Cout;
-  const int ci = (int)(r % Cin);
-  const int t = (int)(r / Cin);
-  float* dst = dW + ((long)co * Cin + ci) * ntaps + t;
-  *dst = accumulate ? (*dst + s) : s;
+struct WgradPlan {
+  int R, strips_per_img, nstrips, nsplit, nslabs;
+  size_t shmem;
+};
+
+WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout, int ntaps) {
+  WgradPlan p;
+  int R = (128 + W / 2) / W;                       // about 128 positions per strip
+  if (R < 1) R = 1;
+  if (R > H) R = H;
+  if (ntaps == 1 && R > 1 && (R & 1)) R -= 1;      // the two row halves of the 1x1 variant stay balanced
+  p.R = R;
+  p.strips_per_img = (H + R - 1) / R;
+  p.nstrips = B * p.strips_per_img;
+  const int pairs = (Cin / 32) * (Cout / 64);
+  const long slab_bytes = (long)ntaps * Cin * Cout * 4 * (ntaps == 1 ? 2 : 1);
+  long max_split = 512 / pairs;                                   // about two workgroups per CU
+  const long budget = (24L << 20) / slab_bytes;                   // keep the partial slabs near 24 MiB
+  if (max_split > budget) max_split = budget;
+  if (max_split < 1) max_split = 1;
+  if (max_split > p.nstrips) max_split = p.nstrips;
+  const int per = (int)((p.nstrips + max_split - 1) / max_split);  // strips per workgroup, evenly dealt
+  p.nsplit = (p.nstrips + per - 1) / per;
+  p.nslabs = p.nsplit * (ntaps == 1 ? 2 : 1);
+  p.shmem = ((size_t)(R + 2) * (W + 2) * 32 + (size_t)R * W * 64) * sizeof(float);
+  return p;
 }
 
 int fill_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout, int ntaps, const int* dh, const int* dw) {
@@ -381,47 +438,46 @@ MMSA_EXPORT int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* 
 }
 
 MMSA_EXPORT long mmsa_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int ntaps, int* nsplit_out) {
-  if (B <= 0 || H <= 0 || Cin % 32 || Cout % 32 || ntaps < 1 || ntaps > MAX_TAPS) return MMSA_ERR_ARG;
-  const int pairs = (Cin / 32) * (Cout / 32);
-  const int rows = B * H;
-  int nsplit = mmsa_cdiv(512, pairs);          // aim for >= 512 workgroups
-  const int max_split = mmsa_cdiv(rows, 4);    // at least one row per wave
-  if (nsplit > max_split) nsplit = max_split;
-  if (nsplit < 1) nsplit = 1;
-  if (nsplit_out) *nsplit_out = nsplit;
-  return (long)nsplit * ntaps * Cin * Cout;
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 64 || (ntaps != 1 && ntaps != 9))
+    return MMSA_ERR_ARG;
+  const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, ntaps);
+  if (nsplit_out) *nsplit_out = p.nslabs;
+  return (long)p.nslabs * ntaps * Cin * Cout;
 }
 
-// dW[Cout][Cin][ntaps] (= or +=) sum over b,h,w of X[b,h+dh,w+dw,cin] * dY[b,h,w,cout]; w < w_valid only.
+// dW[Cout][Cin][ntaps] (= or +=) sum over b,h,w of X[b,h+dh,w+dw,cin] * dY[b,h,w,cout]; ntaps is 9 (offsets within
+// one pixel of the centre) or 1 (the centre), the two shapes the residual blocks need; w_valid must equal W.
 MMSA_EXPORT int mmsa_conv_wgrad(const float* X, const float* dY, float* dW, float* workspace, int B, int H, int W,
                                 int w_valid, int Cin, int Cout, int ntaps, const int* dh, const int* dw,
                                 int accumulate, void* stream) {
   MMSA_REQUIRE(X && dY && dW && workspace && dh && dw);
-  MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && w_valid > 0 && w_valid <= W);
-  MMSA_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0);
-  MMSA_REQUIRE(ntaps == 1 || ntaps == 3 || ntaps == 4 || ntaps == 5 || ntaps == 9);
+  MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && w_valid == W);
+  MMSA_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0);
+  MMSA_REQUIRE(ntaps == 1 || ntaps == 9);
+  for (int i = 0; i < ntaps; ++i) MMSA_REQUIRE(dh[i] >= -1 && dh[i] <= 1 && dw[i] >= -1 && dw[i] <= 1);
   ConvGeom g;
   if (fill_geom(g, B, H, W, Cin, Cout, ntaps, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
-  int nsplit = 1;
-  mmsa_conv_wgrad_workspace_floats(B, H, W, Cin, Cout, ntaps, &nsplit);
+  const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, ntaps);
+  MMSA_REQUIRE(p.shmem <= 150 * 1024);
   hipStream_t s = mmsa_stream(stream);
-  dim3 grid((Cin / 32) * (Cout / 32), nsplit);
-  const size_t shmem = 2 * (size_t)ntaps * 1024 * sizeof(float);
-  switch (ntaps) {
-    case 1: hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), shmem, s, X, dY, workspace, g, w_valid); break;
-    case 3: hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, dim3(256), shmem, s, X, dY, workspace, g, w_valid); break;
-    case 4: hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(256), shmem, s, X, dY, workspace, g, w_valid); break;
-    case 5: hipLaunchKernelGGL(conv_wgrad_kernel<5>, grid, dim3(256), shmem, s, X, dY, workspace, g, w_valid); break;
-    default: {
-      // 9 taps need 72 KiB of LDS for the wave combine
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<9>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
-        return MMSA_ERR_LAUNCH;
-      hipLaunchKernelGGL(conv_wgrad_kernel<9>, grid, dim3(256), shmem, s, X, dY, workspace, g, w_valid);
-    }
+  dim3 grid((Cin / 32) * (Cout / 64), p.nsplit);
+  if (ntaps == 9) {
+    if (p.shmem > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<9>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.shmem) != hipSuccess)
+      return MMSA_ERR_LAUNCH;
+    hipLaunchKernelGGL(conv_wgrad_kernel<9>, grid, dim3(256), p.shmem, s, X, dY, workspace, g, p.R, p.nstrips,
+                       p.strips_per_img);
+  } else {
+    if (p.shmem > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_kernel<1>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.shmem) != hipSuccess)
+      return MMSA_ERR_LAUNCH;
+    hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), p.shmem, s, X, dY, workspace, g, p.R, p.nstrips,
+                       p.strips_per_img);
   }
   const long total = (long)ntaps * Cin * Cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, workspace, dW,
-                     nsplit, ntaps, Cin, Cout, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, dW, p.nslabs,
+                     ntaps, Cin, Cout, accumulate);
   return mmsa_launch_status();
 }

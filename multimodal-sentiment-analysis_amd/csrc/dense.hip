@@ -22,32 +22,45 @@ __device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned 
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
-// Y[b][:] = drop( epi( X[b] W^T + bias ) ).  Saves pre (linear output) and, for LN epilogues, mean / rstd.
-__global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict__ X, int ldx,
-                                                        const float* __restrict__ W, const float* __restrict__ bias,
-                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        float* __restrict__ Y, int ldy, float* __restrict__ pre,
-                                                        float* __restrict__ stats, int K, int N, int epi, float drop_p,
-                                                        unsigned long long seed) {
-  extern __shared__ float sm[];
-  float* xs = sm;          // [K]
-  float* ps = sm + K;      // [N]
-  __shared__ float red[16];
+// out[b][n0 .. n0+63] = X[b] W^T + bias.  grid = (B, ceil(N/64)); every wave owns 16 outputs and computes four of
+// them at a time (independent weight-row loads stay in flight); lanes run along K, so weight rows are read coalesced.
+__global__ __launch_bounds__(256) void dense_matvec_kernel(const float* __restrict__ X, int ldx,
+                                                           const float* __restrict__ W, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int ldo, int K, int N) {
+  extern __shared__ float xs[];  // [K]
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
   for (int k = t; k < K; k += 256) xs[k] = X[(long)b * ldx + k];
   __syncthreads();
-  for (int n = w; n < N; n += 4) {
-    const float* wr = W + (long)n * K;
-    float a = 0.f;
-    for (int k = lane; k < K; k += 64) a = fmaf(wr[k], xs[k], a);
-    a = wave_sum(a);
-    if (lane == 0) {
-      a += bias ? bias[n] : 0.f;
-      ps[n] = a;
-      if (pre) pre[(long)b * N + n] = a;
+  const int nbase = blockIdx.y * 64 + w * 16;
+#pragma unroll 1
+  for (int g4 = 0; g4 < 16; g4 += 4) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* wr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wr[i] = W + (long)min(nbase + g4 + i, N - 1) * K;
+    for (int k = lane; k < K; k += 64) {
+      const float xv = xs[k];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = fmaf(wr[i][k], xv, a[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a[i] = wave_sum(a[i]);
+      const int n = nbase + g4 + i;
+      if (lane == 0 && n < N) out[(long)b * ldo + n] = a[i] + (bias ? bias[n] : 0.f);
     }
   }
-  __syncthreads();
+}
+
+// Y[b][:] = drop( epi( pre[b][:] ) ), one block per utterance; saves mean / rstd for the LayerNorm epilogues.
+__global__ __launch_bounds__(256) void dense_epilogue_kernel(const float* __restrict__ pre,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ Y,
+                                                             int ldy, float* __restrict__ stats, int N, int epi,
+                                                             float drop_p, unsigned long long seed) {
+  __shared__ float red[16];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* ps = pre + (long)b * N;
   float mean = 0.f, rstd = 1.f;
   if (epi == EPI_LN_RELU || epi == EPI_RELU_LN) {
     float s = 0.f;
@@ -81,7 +94,8 @@ __global__ __launch_bounds__(256) void dense_fwd_kernel(const float* __restrict_
 }
 
 // dY[b][:] -> dPre[b][:] (gradient w.r.t. the linear output), dLn[b][:] (gradient w.r.t. the LayerNorm output,
-// LN epilogues only), dX[b][:] (= or +=) dPre W.
+// LN epilogues only), dX[b][:] (= or +=) dPre W.  grid = (B, ceil(K/64)): every block rebuilds the utterance's
+// dPre row in LDS (cheap) and then produces 64 columns of dX, four thread groups splitting the sum over N.
 __global__ __launch_bounds__(256) void dense_bwd_x_kernel(const float* __restrict__ dY, int ldy,
                                                           const float* __restrict__ pre, const float* __restrict__ stats,
                                                           const float* __restrict__ W, const float* __restrict__ gamma,
@@ -92,7 +106,9 @@ __global__ __launch_bounds__(256) void dense_bwd_x_kernel(const float* __restric
   extern __shared__ float sm[];
   float* g = sm;  // [N] gradient w.r.t. linear output
   __shared__ float red[16];
+  __shared__ float part[4][64];
   const int b = blockIdx.x, t = threadIdx.x;
+  const bool first = blockIdx.y == 0;
   const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
   float mean = 0.f, rstd = 1.f;
   if (epi == EPI_LN_RELU || epi == EPI_RELU_LN) {
@@ -108,14 +124,14 @@ __global__ __launch_bounds__(256) void dense_bwd_x_kernel(const float* __restric
     if (epi == EPI_LN_RELU) {
       const float xh = (p - mean) * rstd;
       if (fmaf(xh, gamma[n], beta[n]) <= 0.f) d = 0.f;
-      if (dLn) dLn[(long)b * N + n] = d;
+      if (dLn && first) dLn[(long)b * N + n] = d;
       const float dg = d * gamma[n];
       g[n] = dg;
       s1 += dg;
       s2 = fmaf(dg, xh, s2);
     } else if (epi == EPI_RELU_LN) {
       const float xh = (fmaxf(p, 0.f) - mean) * rstd;
-      if (dLn) dLn[(long)b * N + n] = d;
+      if (dLn && first) dLn[(long)b * N + n] = d;
       const float dg = d * gamma[n];
       g[n] = dg;
       s1 += dg;
@@ -139,11 +155,24 @@ __global__ __launch_bounds__(256) void dense_bwd_x_kernel(const float* __restric
     }
   }
   __syncthreads();
-  for (int n = t; n < N; n += 256) dPre[(long)b * N + n] = g[n];
+  if (first)
+    for (int n = t; n < N; n += 256) dPre[(long)b * N + n] = g[n];
   if (dX) {
-    for (int k = t; k < K; k += 256) {
-      float a = 0.f;
-      for (int n = 0; n < N; ++n) a = fmaf(g[n], W[(long)n * K + k], a);
+    const int kl = t & 63, grp = t >> 6;
+    const int k = blockIdx.y * 64 + kl;
+    float a0 = 0.f, a1 = 0.f;
+    if (k < K) {
+      int n = grp;
+      for (; n + 4 < N; n += 8) {
+        a0 = fmaf(g[n], W[(long)n * K + k], a0);
+        a1 = fmaf(g[n + 4], W[(long)(n + 4) * K + k], a1);
+      }
+      for (; n < N; n += 4) a0 = fmaf(g[n], W[(long)n * K + k], a0);
+    }
+    part[grp][kl] = a0 + a1;
+    __syncthreads();
+    if (grp == 0 && k < K) {
+      const float a = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
       float* dst = dX + (long)b * ldx + k;
       *dst = accumulate_dx ? *dst + a : a;
     }
@@ -161,6 +190,7 @@ __global__ void dense_bwd_w_kernel(const float* __restrict__ dPre, const float* 
   if (i < nk) {
     const int n = (int)(i / K), k = (int)(i - (long)n * K);
     float a = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; ++b) a = fmaf(dPre[(long)b * N + n], X[(long)b * ldx + k], a);
     dW[i] = a;
   } else if (i < nk + N) {
@@ -410,11 +440,23 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
 MMSA_EXPORT int mmsa_dense_fwd(const float* X, int ldx, const float* W, const float* bias, const float* gamma,
                                const float* beta, float* Y, int ldy, float* pre, float* stats, int B, int K, int N,
                                int epilogue, float drop_p, unsigned long long seed, void* stream) {
-  MMSA_REQUIRE(X && W && Y && B > 0 && K > 0 && N > 0 && ldx >= K && ldy >= N && K + N <= 12 * 1024);
+  MMSA_REQUIRE(X && W && Y && B > 0 && B <= 65535 && K > 0 && N > 0 && ldx >= K && ldy >= N && K <= 12 * 1024);
   MMSA_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_RELU && drop_p >= 0.f && drop_p < 1.f);
   if (epilogue == EPI_LN_RELU || epilogue == EPI_RELU_LN) MMSA_REQUIRE(gamma && beta && stats);
-  hipLaunchKernelGGL(dense_fwd_kernel, dim3(B), dim3(256), (size_t)(K + N) * sizeof(float), mmsa_stream(stream), X, ldx,
-                     W, bias, gamma, beta, Y, ldy, pre, stats, K, N, epilogue, drop_p, seed);
+  hipStream_t s = mmsa_stream(stream);
+  const bool plain = epilogue == EPI_NONE && drop_p == 0.f;
+  if (!plain) MMSA_REQUIRE(pre != nullptr);     // the linear output is kept for the backward pass
+  dim3 grid(B, mmsa_cdiv(N, 64));
+  hipLaunchKernelGGL(dense_matvec_kernel, grid, dim3(256), (size_t)K * sizeof(float), s, X, ldx, W, bias,
+                     plain ? Y : pre, plain ? ldy : N, K, N);
+  if (plain) {
+    if (pre && hipMemcpy2DAsync(pre, (size_t)N * 4, Y, (size_t)ldy * 4, (size_t)N * 4, B, hipMemcpyDeviceToDevice, s) !=
+                   hipSuccess)
+      return MMSA_ERR_LAUNCH;
+  } else {
+    hipLaunchKernelGGL(dense_epilogue_kernel, dim3(B), dim3(256), 0, s, pre, gamma, beta, Y, ldy, stats, N, epilogue,
+                       drop_p, seed);
+  }
   return mmsa_launch_status();
 }
 
@@ -424,14 +466,15 @@ MMSA_EXPORT int mmsa_dense_bwd(const float* dY, int ldy, const float* X, int ldx
                                const float* W, const float* gamma, const float* beta, float* dPre, float* dLn, float* dX,
                                int lddx, float* dW, float* db, float* dgamma, float* dbeta, int B, int K, int N,
                                int epilogue, float drop_p, unsigned long long seed, int accumulate_dx, void* stream) {
-  MMSA_REQUIRE(dY && X && W && dPre && B > 0 && K > 0 && N > 0 && N <= 12 * 1024);
+  MMSA_REQUIRE(dY && X && W && dPre && B > 0 && B <= 65535 && K > 0 && N > 0 && N <= 12 * 1024);
   MMSA_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_RELU);
   const bool ln = epilogue == EPI_LN_RELU || epilogue == EPI_RELU_LN;
   if (ln) MMSA_REQUIRE(pre && stats && gamma && beta && dLn);
   if (epilogue == EPI_RELU) MMSA_REQUIRE(pre != nullptr);
   hipStream_t s = mmsa_stream(stream);
-  hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(B), dim3(256), (size_t)N * sizeof(float), s, dY, ldy, pre, stats, W, gamma,
-                     beta, dPre, ln ? dLn : nullptr, dX, lddx, K, N, epilogue, drop_p, seed, accumulate_dx);
+  hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(B, dX ? mmsa_cdiv(K, 64) : 1), dim3(256), (size_t)N * sizeof(float), s, dY,
+                     ldy, pre, stats, W, gamma, beta, dPre, ln ? dLn : nullptr, dX, lddx, K, N, epilogue, drop_p, seed,
+                     accumulate_dx);
   if (dW) {
     const long total = (long)N * K + N;
     hipLaunchKernelGGL(dense_bwd_w_kernel, dim3(mmsa_cdiv(total, 256)), dim3(256), 0, s, dPre, dLn, pre, stats, X, ldx,

@@ -47,16 +47,22 @@ __global__ __launch_bounds__(256) void chunk_sumsq_kernel(const float* __restric
 }
 
 // per-tensor norms from chunk sums; out_sum = sum_t norm_t (fp32, registration order), out_l2 = sqrt(sum_t norm_t^2)
-__global__ void tensor_norms_kernel(const double* __restrict__ chunk_ss, const int* __restrict__ tensor_first_chunk,
-                                    int ntensors, float* __restrict__ tnorm, float* __restrict__ out_sum,
-                                    float* __restrict__ out_l2) {
+__global__ __launch_bounds__(1024) void tensor_norms_kernel(const double* __restrict__ chunk_ss,
+                                                            const int* __restrict__ tensor_first_chunk, int ntensors,
+                                                            float* __restrict__ tnorm, float* __restrict__ out_sum,
+                                                            float* __restrict__ out_l2) {
+  // one wave per tensor (16 waves take tensors round-robin), lanes stride over the tensor's chunk sums
   __shared__ float nrm[1024];
-  for (int t = threadIdx.x; t < ntensors; t += blockDim.x) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int t = w; t < ntensors; t += 16) {
     double s = 0.0;
-    for (int c = tensor_first_chunk[t]; c < tensor_first_chunk[t + 1]; ++c) s += chunk_ss[c];
-    const float v = (float)sqrt(s);
-    nrm[t] = v;
-    if (tnorm) tnorm[t] = v;
+    for (int c = tensor_first_chunk[t] + lane; c < tensor_first_chunk[t + 1]; c += 64) s += chunk_ss[c];
+    s = wave_sum_d(s);
+    if (lane == 0) {
+      const float v = (float)sqrt(s);
+      nrm[t] = v;
+      if (tnorm) tnorm[t] = v;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -100,32 +106,58 @@ __global__ void scale_inplace_by_state_kernel(float* __restrict__ g, long n, con
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) g[i] *= coef;
 }
 
-// p, m, v updated in place from g * clip (+ optional L2-term gradient lambda * p / ||p||, computed on the fly)
+__device__ __forceinline__ void adamw_update(float& p, float g, float& m, float& v, float coef, float clip, float decay,
+                                             float beta1, float beta2, float bc2s, float eps, float step_size) {
+  const float gr = fmaf(coef, p, g) * clip;      // data gradient + lambda * p / ||p||, then the clip coefficient
+  p *= decay;
+  m = m + (1.f - beta1) * (gr - m);
+  v = v * beta2 + (1.f - beta2) * gr * gr;
+  p -= step_size * (m / (sqrtf(v) / bc2s + eps));
+}
+
+// One workgroup per chunk of the flat buffer (a chunk never straddles tensors): p, m, v updated in place from
+// (g + lambda * p / ||p||_tensor) * clip.  The regulariser's gradient is formed on the fly, so it is never stored.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                    float* __restrict__ m, float* __restrict__ v, long n4,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    const long long* __restrict__ chunk_off,
+                                                    const int* __restrict__ chunk_len,
+                                                    const int* __restrict__ chunk_tensor,
+                                                    const float* __restrict__ tnorm, float lambda,
                                                     const float* __restrict__ state, float lr, float beta1, float beta2,
                                                     float eps, float wd) {
   const float clip = state[ST_CLIP], bc1 = state[ST_BC1], bc2s = state[ST_BC2S];
   const float step_size = lr / bc1;
   const float decay = 1.f - lr * wd;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
-    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
-    f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
-    f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+  const int c = blockIdx.x;
+  const long off = chunk_off[c];
+  const int n = chunk_len[c];
+  float coef = 0.f;
+  if (tnorm && lambda != 0.f) {
+    const float nm = tnorm[chunk_tensor[c]];
+    coef = nm > 0.f ? lambda / nm : 0.f;
+  }
+  const int n4 = n >> 2;
+  f32x4* p4 = reinterpret_cast<f32x4*>(p + off);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g + off);
+  f32x4* m4 = reinterpret_cast<f32x4*>(m + off);
+  f32x4* v4 = reinterpret_cast<f32x4*>(v + off);
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    f32x4 pp = p4[i], mm = m4[i], vv = v4[i];
+    const f32x4 gg = g4[i];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float gr = gg[k] * clip;
-      pp[k] *= decay;
-      mm[k] = mm[k] + (1.f - beta1) * (gr - mm[k]);
-      vv[k] = vv[k] * beta2 + (1.f - beta2) * gr * gr;
-      const float denom = sqrtf(vv[k]) / bc2s + eps;
-      pp[k] -= step_size * (mm[k] / denom);
+      float pk = pp[k], mk = mm[k], vk = vv[k];
+      adamw_update(pk, gg[k], mk, vk, coef, clip, decay, beta1, beta2, bc2s, eps, step_size);
+      pp[k] = pk;
+      mm[k] = mk;
+      vv[k] = vk;
     }
-    reinterpret_cast<f32x4*>(p)[i] = pp;
-    reinterpret_cast<f32x4*>(m)[i] = mm;
-    reinterpret_cast<f32x4*>(v)[i] = vv;
+    p4[i] = pp;
+    m4[i] = mm;
+    v4[i] = vv;
   }
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256)
+    adamw_update(p[off + i], g[off + i], m[off + i], v[off + i], coef, clip, decay, beta1, beta2, bc2s, eps, step_size);
 }
 
 __global__ void add_scaled_scalar_kernel(float* __restrict__ dst, const float* __restrict__ a,
@@ -144,7 +176,7 @@ MMSA_EXPORT int mmsa_param_norms(const float* p, const long long* chunk_off, con
   hipStream_t s = mmsa_stream(stream);
   hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, p, (const float*)nullptr,
                      (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss);
-  hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(256), 0, s, chunk_ss, tensor_first_chunk, ntensors, tnorm,
+  hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors, tnorm,
                      sum_out, (float*)nullptr);
   return mmsa_launch_status();
 }
@@ -158,33 +190,35 @@ MMSA_EXPORT int mmsa_l2_grad_add(float* g, const float* p, const float* tnorm, f
   return mmsa_launch_status();
 }
 
-// total gradient norm = || (||g_1||, ..., ||g_T||) ||_2  -> state[4]
-MMSA_EXPORT int mmsa_grad_norm(const float* g, const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
-                               int nchunks, const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* state,
+// total gradient norm = || (||g_1||, ..., ||g_T||) ||_2  -> state[4].  When p / tnorm are given the norm is taken of
+// g + lambda * p / ||p|| (the regulariser's gradient folded in without materialising it).
+MMSA_EXPORT int mmsa_grad_norm(const float* g, const float* p, const float* tnorm, float lambda,
+                               const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,
+                               const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* state,
                                void* stream) {
   MMSA_REQUIRE(g && chunk_off && chunk_len && chunk_tensor && tensor_first_chunk && chunk_ss && state);
   MMSA_REQUIRE(nchunks > 0 && ntensors > 0 && ntensors <= 1024);
+  MMSA_REQUIRE((p == nullptr) == (tnorm == nullptr));
   hipStream_t s = mmsa_stream(stream);
-  hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, g, (const float*)nullptr,
-                     (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss);
-  hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(256), 0, s, chunk_ss, tensor_first_chunk, ntensors,
+  hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, g, p, tnorm, lambda, chunk_off, chunk_len,
+                     chunk_tensor, chunk_ss);
+  hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors,
                      (float*)nullptr, (float*)nullptr, state + ST_GNORM);
   return mmsa_launch_status();
 }
 
-// One AdamW step over the flat buffers (n floats, n % 4 == 0).  state[0] (step count) advances by one; the clip
-// coefficient is derived from state[4] (call mmsa_grad_norm first) when do_clip != 0.
-MMSA_EXPORT int mmsa_adamw_step(float* p, const float* g, float* m, float* v, long n, float* state, float lr,
-                                float beta1, float beta2, float eps, float weight_decay, float max_norm, int do_clip,
-                                void* stream) {
-  MMSA_REQUIRE(p && g && m && v && state && n > 0 && n % 4 == 0);
+// One AdamW step over the chunks of the flat buffers.  state[0] (step count) advances by one; the clip coefficient
+// is derived from state[4] (call mmsa_grad_norm first) when do_clip != 0.  With tnorm given, lambda * p / ||p|| is
+// added to every gradient element on the fly (pass null / 0 for plain AdamW).
+MMSA_EXPORT int mmsa_adamw_step(float* p, const float* g, float* m, float* v, const long long* chunk_off,
+                                const int* chunk_len, const int* chunk_tensor, int nchunks, const float* tnorm,
+                                float lambda, float* state, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, float max_norm, int do_clip, void* stream) {
+  MMSA_REQUIRE(p && g && m && v && state && chunk_off && chunk_len && chunk_tensor && nchunks > 0);
   hipStream_t s = mmsa_stream(stream);
   hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, s, state, beta1, beta2, max_norm, do_clip);
-  const long n4 = n / 4;
-  long blocks = (n4 + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n4, state, lr, beta1, beta2, eps,
-                     weight_decay);
+  hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, s, p, g, m, v, chunk_off, chunk_len, chunk_tensor, tnorm,
+                     lambda, state, lr, beta1, beta2, eps, weight_decay);
   return mmsa_launch_status();
 }
 

@@ -32,48 +32,69 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const long long* __res
 __global__ void bias_relu_maxtime_kernel(const float* __restrict__ y, const float* __restrict__ bias,
                                          float* __restrict__ feat, int* __restrict__ arg, int B, int L, int Lout,
                                          int F, int ldf) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * F) return;
-  const int b = i / F, f = i - b * F;
-  const float bs = bias[f];
+  // grid = (ceil(F/64), B); 64 filters per block, four thread groups scan interleaved time steps, then the
+  // (value, first index) pairs are merged in LDS: larger value wins, equal values keep the earlier step.
+  __shared__ float sv[4][64];
+  __shared__ int si[4][64];
+  const int fl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + fl, b = blockIdx.y;
   float best = -1.f;
   int bt = 0;
-  for (int t = 0; t < Lout; ++t) {
-    const float v = fmaxf(y[((long)b * L + t) * F + f] + bs, 0.f);
-    if (v > best) { best = v; bt = t; }
+  if (f < F) {
+    const float bs = bias[f];
+    const float* yp = y + (long)b * L * F + f;
+#pragma unroll 4
+    for (int t = grp; t < Lout; t += 4) {
+      const float v = fmaxf(yp[(long)t * F] + bs, 0.f);
+      if (v > best) { best = v; bt = t; }
+    }
   }
-  feat[(long)b * ldf + f] = best;
-  arg[(long)b * ldf + f] = bt;
+  sv[grp][fl] = best;
+  si[grp][fl] = bt;
+  __syncthreads();
+  if (grp == 0 && f < F) {
+#pragma unroll
+    for (int g = 1; g < 4; ++g) {
+      const float v = sv[g][fl];
+      const int t = si[g][fl];
+      if (v > best || (v == best && t < bt)) { best = v; bt = t; }
+    }
+    feat[(long)b * ldf + f] = best;
+    arg[(long)b * ldf + f] = bt;
+  }
 }
 
 // dW[f][c][j] = sum_b g[b][f] * emb[b][t*(b,f)+j][c];  dbias[f] = sum_b g[b][f];  g = dfeat where feat > 0.
-// grid = F blocks, block = E threads (c).
+// grid = F blocks, block = E threads (c).  The per-utterance (g, t*) pairs are staged in LDS first so the
+// embedding loads are unconditional and independent (the compiler keeps several in flight).
 template <int K>
 __global__ void text_bwd_w_kernel(const float* __restrict__ dfeat, const float* __restrict__ feat,
                                   const int* __restrict__ arg, const float* __restrict__ emb, float* __restrict__ dW,
                                   float* __restrict__ dbias, int B, int L, int E, int ldf) {
+  extern __shared__ float sm[];
+  float* gs = sm;                                  // [B]
+  int* ts = reinterpret_cast<int*>(sm + B);        // [B]
   const int f = blockIdx.x, c = threadIdx.x;
+  for (int b = c; b < B; b += blockDim.x) {
+    const float ft = feat[(long)b * ldf + f];
+    gs[b] = ft > 0.f ? dfeat[(long)b * ldf + f] : 0.f;
+    ts[b] = arg[(long)b * ldf + f];
+  }
+  __syncthreads();
   float acc[K];
 #pragma unroll
   for (int j = 0; j < K; ++j) acc[j] = 0.f;
   float gb = 0.f;
+#pragma unroll 4
   for (int b = 0; b < B; ++b) {
-    const float ft = feat[(long)b * ldf + f];
-    if (ft > 0.f) {  // uniform across the block
-      const float g = dfeat[(long)b * ldf + f];
-      const int t0 = arg[(long)b * ldf + f];
-      gb += g;
-      if (c < E) {
-        const float* e = emb + ((long)b * L + t0) * E + c;
+    const float g = gs[b];
+    const float* e = emb + ((long)b * L + ts[b]) * E + c;
+    gb += g;
 #pragma unroll
-        for (int j = 0; j < K; ++j) acc[j] = fmaf(g, e[(long)j * E], acc[j]);
-      }
-    }
+    for (int j = 0; j < K; ++j) acc[j] = fmaf(g, e[(long)j * E], acc[j]);
   }
-  if (c < E) {
 #pragma unroll
-    for (int j = 0; j < K; ++j) dW[((long)f * E + c) * K + j] = acc[j];
-  }
+  for (int j = 0; j < K; ++j) dW[((long)f * E + c) * K + j] = acc[j];
   if (c == 0) dbias[f] = gb;
 }
 
@@ -84,44 +105,61 @@ struct TextConvs {
   const float* wp[4];  // packed [j][F][E]
 };
 
-// dEmb rows accumulated in LDS per utterance, then scatter-added into the table gradient (skip padding rows).
-// grid = B, block = E threads; LDS = TL*E floats + TL ints.
-__global__ void text_bwd_emb_kernel(const float* __restrict__ dfeat, const float* __restrict__ feat,
-                                    const int* __restrict__ arg, const long long* __restrict__ ids, TextConvs cv,
-                                    float* __restrict__ dtable, int L, int E, int F, int ldf, long padding_idx, int TL) {
-  extern __shared__ float acc[];  // [TL][E]
-  int* touched = reinterpret_cast<int*>(acc + (long)TL * E);
-  const int b = blockIdx.x, c = threadIdx.x;
-  for (int t0 = 0; t0 < L; t0 += TL) {
-    for (int t = 0; t < TL; ++t) acc[(long)t * E + c] = 0.f;
-    if (c < TL) touched[c] = 0;
-    __syncthreads();
+// Gradient of one gathered embedding row: grid = (L, B), block = E threads (channel c), one row (b, t) each.
+//   dEmb[b][t][c] = sum over convs i, filters f, taps j with arg[b][i,f] + j == t of  g[b][i,f] * W_i[f][c][j]
+// The utterance's (g, arg) pairs are staged in LDS; the threads split the filter range four ways so that the
+// data-dependent weight-row loads of up to four matches are in flight at once, and the four partial rows are
+// combined in fixed order.  Rows of padding tokens are skipped; the finished row is added to the table gradient
+// with float atomics (tokens repeated across the batch meet there).
+__global__ __launch_bounds__(256) void text_bwd_emb_kernel(const float* __restrict__ dfeat,
+                                                           const float* __restrict__ feat,
+                                                           const int* __restrict__ arg,
+                                                           const long long* __restrict__ ids, TextConvs cv,
+                                                           float* __restrict__ dtable, int L, int E, int F, int ldf,
+                                                           long padding_idx) {
+  extern __shared__ float sm[];
+  const int nf = cv.nconv * F;
+  float* gs = sm;                                   // [nf]
+  int* as = reinterpret_cast<int*>(sm + nf);        // [nf]
+  float* part = sm + 2 * nf;                        // [4][E]
+  const int t = blockIdx.x, b = blockIdx.y;
+  const long long id = ids[(long)b * L + t];
+  if (id == padding_idx) return;                    // uniform: the whole block leaves
+  for (int i = threadIdx.x; i < nf; i += blockDim.x) {
+    const int ci = i / F, f = i - ci * F;
+    const long o = (long)b * ldf + cv.feat_off[ci] + f;
+    gs[i] = feat[o] > 0.f ? dfeat[o] : 0.f;
+    as[i] = arg[o];
+  }
+  __syncthreads();
+  const int quarter = threadIdx.x / (blockDim.x / 4);          // which slice of the filter range
+  const int qthreads = blockDim.x / 4;                         // threads per slice
+  const int c0 = threadIdx.x - quarter * qthreads;             // first channel of this thread
+  const int fchunk = (F + 3) / 4;
+  bool any = false;
+  for (int cbase = 0; cbase < E; cbase += qthreads) {
+    const int c = cbase + c0;
+    float acc = 0.f;
     for (int ci = 0; ci < cv.nconv; ++ci) {
       const int K = cv.k[ci];
       const float* wp = cv.wp[ci];
-      for (int f = 0; f < F; ++f) {
-        const long o = (long)b * ldf + cv.feat_off[ci] + f;
-        if (feat[o] > 0.f) {  // uniform
-          const float g = dfeat[o];
-          const int ts = arg[o];
-          for (int j = 0; j < K; ++j) {
-            const int t = ts + j - t0;
-            if (t >= 0 && t < TL) {
-              acc[(long)t * E + c] = fmaf(g, wp[((long)j * F + f) * E + c], acc[(long)t * E + c]);
-              touched[t] = 1;  // same value from every thread
-            }
-          }
+      const int f1 = min(F, (quarter + 1) * fchunk);
+      for (int f = quarter * fchunk; f < f1; ++f) {
+        const int j = t - as[ci * F + f];
+        const float g = gs[ci * F + f];
+        if (j >= 0 && j < K && g != 0.f) {            // uniform within the slice's wave(s)
+          acc = fmaf(g, wp[((long)j * F + f) * E + c], acc);
+          any = true;
         }
       }
     }
-    __syncthreads();
-    for (int t = 0; t < TL && t0 + t < L; ++t) {
-      if (touched[t]) {
-        const long long id = ids[(long)b * L + t0 + t];
-        if (id != padding_idx) atomicAdd(dtable + id * E + c, acc[(long)t * E + c]);
-      }
-    }
-    __syncthreads();
+    part[quarter * E + c] = acc;
+  }
+  const int hit = __syncthreads_or(any ? 1 : 0);
+  if (!hit) return;
+  for (int c = threadIdx.x; c < E; c += blockDim.x) {
+    const float v = (part[c] + part[E + c]) + (part[2 * E + c] + part[3 * E + c]);
+    atomicAdd(dtable + id * E + c, v);
   }
 }
 
@@ -139,7 +177,8 @@ MMSA_EXPORT int mmsa_embedding_gather(const long long* ids, const float* table, 
 MMSA_EXPORT int mmsa_bias_relu_maxtime(const float* y, const float* bias, float* feat, int* arg, int B, int L, int Lout,
                                        int F, int ldf, void* stream) {
   MMSA_REQUIRE(y && bias && feat && arg && B > 0 && L > 0 && Lout > 0 && Lout <= L && F > 0 && ldf >= F);
-  hipLaunchKernelGGL(bias_relu_maxtime_kernel, dim3(mmsa_cdiv((long)B * F, 256)), dim3(256), 0, mmsa_stream(stream), y,
+  MMSA_REQUIRE(B <= 65535);
+  hipLaunchKernelGGL(bias_relu_maxtime_kernel, dim3(mmsa_cdiv(F, 64), B), dim3(256), 0, mmsa_stream(stream), y,
                      bias, feat, arg, B, L, Lout, F, ldf);
   return mmsa_launch_status();
 }
@@ -152,7 +191,7 @@ MMSA_EXPORT int mmsa_text_bwd(const float* dfeat, const float* feat, const int* 
                               const float* const* wp, float* const* dW, float* const* dbias, float* dtable, int B, int L,
                               int E, int F, int ldf, long padding_idx, void* stream) {
   MMSA_REQUIRE(dfeat && feat && arg && emb && ids && ksize && feat_off && wp && dW && dbias && dtable);
-  MMSA_REQUIRE(nconv >= 1 && nconv <= 4 && B > 0 && L > 0 && E > 0 && E <= 1024 && E % 64 == 0 && F > 0);
+  MMSA_REQUIRE(nconv >= 1 && nconv <= 4 && B > 0 && B <= 65535 && L > 0 && E > 0 && E <= 1024 && E % 64 == 0 && F > 0);
   hipStream_t s = mmsa_stream(stream);
   TextConvs cv;
   cv.nconv = nconv;
@@ -161,30 +200,25 @@ MMSA_EXPORT int mmsa_text_bwd(const float* dfeat, const float* feat, const int* 
     cv.feat_off[i] = i < nconv ? feat_off[i] : 0;
     cv.wp[i] = i < nconv ? wp[i] : nullptr;
   }
+  const size_t wsh = (size_t)B * 8;   // (g, t*) per utterance
+  MMSA_REQUIRE(wsh <= 48 * 1024);
   for (int i = 0; i < nconv; ++i) {
     const float* df = dfeat + feat_off[i];
     const float* ft = feat + feat_off[i];
     const int* ag = arg + feat_off[i];
     switch (ksize[i]) {
-      case 2: hipLaunchKernelGGL(text_bwd_w_kernel<2>, dim3(F), dim3(E), 0, s, df, ft, ag, emb, dW[i], dbias[i], B, L, E, ldf); break;
-      case 3: hipLaunchKernelGGL(text_bwd_w_kernel<3>, dim3(F), dim3(E), 0, s, df, ft, ag, emb, dW[i], dbias[i], B, L, E, ldf); break;
-      case 4: hipLaunchKernelGGL(text_bwd_w_kernel<4>, dim3(F), dim3(E), 0, s, df, ft, ag, emb, dW[i], dbias[i], B, L, E, ldf); break;
-      case 5: hipLaunchKernelGGL(text_bwd_w_kernel<5>, dim3(F), dim3(E), 0, s, df, ft, ag, emb, dW[i], dbias[i], B, L, E, ldf); break;
-      case 6: hipLaunchKernelGGL(text_bwd_w_kernel<6>, dim3(F), dim3(E), 0, s, df, ft, ag, emb, dW[i], dbias[i], B, L, E, ldf); break;
-      case 7: hipLaunchKernelGGL(text_bwd_w_kernel<7>, dim3(F), dim3(E), 0, s, df, ft, ag, emb, dW[i], dbias[i], B, L, E, ldf); break;
+      case 2: hipLaunchKernelGGL(text_bwd_w_kernel<2>, dim3(F), dim3(E), wsh, s, df, ft, ag, emb, dW[i], dbias[i], B, L, E, ldf); break;
+      case 3: hipLaunchKernelGGL(text_bwd_w_kernel<3>, dim3(F), dim3(E), wsh, s, df, ft, ag, emb, dW[i], dbias[i], B, L, E, ldf); break;
+      case 4: hipLaunchKernelGGL(text_bwd_w_kernel<4>, dim3(F), dim3(E), wsh, s, df, ft, ag, emb, dW[i], dbias[i], B, L, E, ldf); break;
+      case 5: hipLaunchKernelGGL(text_bwd_w_kernel<5>, dim3(F), dim3(E), wsh, s, df, ft, ag, emb, dW[i], dbias[i], B, L, E, ldf); break;
+      case 6: hipLaunchKernelGGL(text_bwd_w_kernel<6>, dim3(F), dim3(E), wsh, s, df, ft, ag, emb, dW[i], dbias[i], B, L, E, ldf); break;
+      case 7: hipLaunchKernelGGL(text_bwd_w_kernel<7>, dim3(F), dim3(E), wsh, s, df, ft, ag, emb, dW[i], dbias[i], B, L, E, ldf); break;
       default: return MMSA_ERR_ARG;
     }
   }
-  // rows of dEmb held in LDS at a time: as many as fit in 128 KiB
-  int TL = (128 * 1024) / (E * (int)sizeof(float));
-  if (TL > L) TL = L;
-  if (TL > E) TL = E;  // the touched[] flags are cleared by threads c < TL
-  MMSA_REQUIRE(TL >= 1);
-  const size_t shmem = (size_t)TL * E * sizeof(float) + (size_t)TL * sizeof(int);
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(text_bwd_emb_kernel),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
-    return MMSA_ERR_LAUNCH;
-  hipLaunchKernelGGL(text_bwd_emb_kernel, dim3(B), dim3(E), shmem, s, dfeat, feat, arg, ids, cv, dtable, L, E, F, ldf,
-                     padding_idx, TL);
+  const size_t shmem = ((size_t)2 * nconv * F + (size_t)4 * E) * sizeof(float);
+  MMSA_REQUIRE(shmem <= 48 * 1024);
+  hipLaunchKernelGGL(text_bwd_emb_kernel, dim3(L, B), dim3(256), shmem, s, dfeat, feat, arg, ids, cv, dtable, L, E, F,
+                     ldf, padding_idx);
   return mmsa_launch_status();
 }

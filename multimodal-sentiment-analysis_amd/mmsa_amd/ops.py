@@ -390,18 +390,22 @@ def l2_grad_add(gflat, pflat, tnorm, lam, table):
               _chk(table.chunk_len, torch.int32), _chk(table.chunk_tensor, torch.int32), table.nchunks, _stream())
 
 
-def grad_norm(gflat, table, state):
-    _lib.call("mmsa_grad_norm", _chk(gflat), _chk(table.chunk_off, torch.int64), _chk(table.chunk_len, torch.int32),
-              _chk(table.chunk_tensor, torch.int32), table.nchunks, _chk(table.tensor_first_chunk, torch.int32),
-              table.ntensors, _chk(table.chunk_ss, torch.float64), _chk(state), _stream())
+def grad_norm(gflat, table, state, pflat=None, tnorm=None, lam=0.0):
+    """state[4] <- global norm of gflat (+ lam * p / ||p|| per tensor when pflat / tnorm are given)."""
+    _lib.call("mmsa_grad_norm", _chk(gflat), _opt(pflat), _opt(tnorm), float(lam), _chk(table.chunk_off, torch.int64),
+              _chk(table.chunk_len, torch.int32), _chk(table.chunk_tensor, torch.int32), table.nchunks,
+              _chk(table.tensor_first_chunk, torch.int32), table.ntensors, _chk(table.chunk_ss, torch.float64),
+              _chk(state), _stream())
 
 
-def adamw_step(p, g, m, v, state, lr, beta1, beta2, eps, wd, max_norm, do_clip):
+def adamw_step(p, g, m, v, table, state, lr, beta1, beta2, eps, wd, max_norm, do_clip, tnorm=None, lam=0.0):
     n = p.numel()
     if g.numel() != n or m.numel() != n or v.numel() != n or state.numel() < 8:
         raise ValueError("adamw_step: size mismatch")
-    _lib.call("mmsa_adamw_step", _chk(p), _chk(g), _chk(m), _chk(v), n, _chk(state), float(lr), float(beta1),
-              float(beta2), float(eps), float(wd), float(max_norm), int(do_clip), _stream())
+    _lib.call("mmsa_adamw_step", _chk(p), _chk(g), _chk(m), _chk(v), _chk(table.chunk_off, torch.int64),
+              _chk(table.chunk_len, torch.int32), _chk(table.chunk_tensor, torch.int32), table.nchunks, _opt(tnorm),
+              float(lam), _chk(state), float(lr), float(beta1), float(beta2), float(eps), float(wd), float(max_norm),
+              int(do_clip), _stream())
 
 
 def scale_by_state(g, state, idx):

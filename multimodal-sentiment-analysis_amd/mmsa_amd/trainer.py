@@ -71,9 +71,7 @@ class TrainStep:
         model._backward(run, d, self.grads, self.ws)
         if self.world > 1:
             self._allreduce()
-        if run.l2:
-            ops.l2_grad_add(self.g, self.arena.flat, self.arena.tnorm, L2_LAMBDA, self.arena.table)
-        self._update()
+        self._update(run.l2)
         self.loss = run.loss
         self.logits = run.head.logits
         self.probs = run.head.probs
@@ -82,12 +80,16 @@ class TrainStep:
         for lo, hi in self._buckets:
             torch.distributed.all_reduce(self.g[lo:hi], group=self.pg)
 
-    def _update(self):
+    def _update(self, l2: bool):
+        """Clip + AdamW over the flat buffers.  self.g holds the DATA gradient only: the regulariser's gradient
+        0.001 * p / ||p|| (per-tensor norms were computed by the forward pass) is folded into both kernels."""
+        a = self.arena
         do_clip = self.max_norm is not None
+        tn, lam = (a.tnorm, L2_LAMBDA) if l2 else (None, 0.0)
         if do_clip:
-            ops.grad_norm(self.g, self.arena.table, self.state)
-        ops.adamw_step(self.arena.flat, self.g, self.m, self.v, self.state, self.lr, self.betas[0], self.betas[1],
-                       self.eps, self.wd, self.max_norm if do_clip else 0.0, do_clip)
+            ops.grad_norm(self.g, a.table, self.state, a.flat if l2 else None, tn, lam)
+        ops.adamw_step(a.flat, self.g, self.m, self.v, a.table, self.state, self.lr, self.betas[0], self.betas[1],
+                       self.eps, self.wd, self.max_norm if do_clip else 0.0, do_clip, tn, lam)
 
     # ------------------------------------------------------------------ public API
     def step(self, audio=None, input_ids=None, labels=None, wave=None):
