@@ -90,7 +90,7 @@ def main():
     torch.manual_seed(42)
     model = MultimodalSentimentModel("both", audio_dropout=0.0, text_dropout=0.0, fusion_dropout=0.0).to(dev).train()
     fe = LogMelFrontEnd(dev)
-    use_graph = (not args.no_graph) and world == 1
+    use_graph = not args.no_graph
     ts = TrainStep(model, lr=1e-3, weight_decay=1e-4, max_norm=1.0, frontend=fe, use_graph=use_graph)
 
     batches = []

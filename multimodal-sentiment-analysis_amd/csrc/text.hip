@@ -105,12 +105,13 @@ struct TextConvs {
   const float* wp[4];  // packed [j][F][E]
 };
 
-// Gradient of one gathered embedding row: grid = (L, B), block = E threads (channel c), one row (b, t) each.
+// Gradient of one gathered embedding row: grid = (L, B), one row (b, t) per workgroup.
 //   dEmb[b][t][c] = sum over convs i, filters f, taps j with arg[b][i,f] + j == t of  g[b][i,f] * W_i[f][c][j]
-// The utterance's (g, arg) pairs are staged in LDS; the threads split the filter range four ways so that the
-// data-dependent weight-row loads of up to four matches are in flight at once, and the four partial rows are
-// combined in fixed order.  Rows of padding tokens are skipped; the finished row is added to the table gradient
-// with float atomics (tokens repeated across the batch meet there).
+// Phase 1: the threads test the utterance's (conv, filter) pairs in parallel and compact the matching ones into
+// an LDS list (ballot + prefix count, so the list order is the pair order: deterministic).  Phase 2: thread c
+// walks the list four entries at a time, so four coalesced weight-row loads are in flight per step.
+// Rows of padding tokens are skipped; the finished row is added to the table gradient with float atomics
+// (tokens repeated across the batch meet there).
 __global__ __launch_bounds__(256) void text_bwd_emb_kernel(const float* __restrict__ dfeat,
                                                            const float* __restrict__ feat,
                                                            const int* __restrict__ arg,
@@ -119,47 +120,72 @@ __global__ __launch_bounds__(256) void text_bwd_emb_kernel(const float* __restri
                                                            long padding_idx) {
   extern __shared__ float sm[];
   const int nf = cv.nconv * F;
-  float* gs = sm;                                   // [nf]
-  int* as = reinterpret_cast<int*>(sm + nf);        // [nf]
-  float* part = sm + 2 * nf;                        // [4][E]
+  float* lg = sm;                                       // [nf + 4] gradient of the matching pair
+  int* lci = reinterpret_cast<int*>(sm + nf + 4);       // [nf + 4] which conv
+  int* loff = lci + nf + 4;                             // [nf + 4] offset of the weight row inside that conv's pack
+  __shared__ int wave_cnt[4];
   const int t = blockIdx.x, b = blockIdx.y;
   const long long id = ids[(long)b * L + t];
-  if (id == padding_idx) return;                    // uniform: the whole block leaves
-  for (int i = threadIdx.x; i < nf; i += blockDim.x) {
-    const int ci = i / F, f = i - ci * F;
-    const long o = (long)b * ldf + cv.feat_off[ci] + f;
-    gs[i] = feat[o] > 0.f ? dfeat[o] : 0.f;
-    as[i] = arg[o];
-  }
-  __syncthreads();
-  const int quarter = threadIdx.x / (blockDim.x / 4);          // which slice of the filter range
-  const int qthreads = blockDim.x / 4;                         // threads per slice
-  const int c0 = threadIdx.x - quarter * qthreads;             // first channel of this thread
-  const int fchunk = (F + 3) / 4;
-  bool any = false;
-  for (int cbase = 0; cbase < E; cbase += qthreads) {
-    const int c = cbase + c0;
-    float acc = 0.f;
-    for (int ci = 0; ci < cv.nconv; ++ci) {
-      const int K = cv.k[ci];
-      const float* wp = cv.wp[ci];
-      const int f1 = min(F, (quarter + 1) * fchunk);
-      for (int f = quarter * fchunk; f < f1; ++f) {
-        const int j = t - as[ci * F + f];
-        const float g = gs[ci * F + f];
-        if (j >= 0 && j < K && g != 0.f) {            // uniform within the slice's wave(s)
-          acc = fmaf(g, wp[((long)j * F + f) * E + c], acc);
-          any = true;
+  if (id == padding_idx) return;                        // uniform: the whole block leaves
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  int count = 0;
+  for (int base = 0; base < nf; base += 256) {
+    const int e = base + tid;
+    bool flag = false;
+    float g = 0.f;
+    int ci = 0, off = 0;
+    if (e < nf) {
+      ci = e / F;
+      const int f = e - ci * F;
+      const long o = (long)b * ldf + cv.feat_off[ci] + f;
+      if (feat[o] > 0.f) {
+        const int j = t - arg[o];
+        if (j >= 0 && j < cv.k[ci]) {
+          g = dfeat[o];
+          off = (j * F + f) * E;
+          flag = g != 0.f;
         }
       }
     }
-    part[quarter * E + c] = acc;
+    const unsigned long long mask = __ballot(flag);
+    const int prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[w] = __popcll(mask);
+    __syncthreads();
+    int before = count, total = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int n = wave_cnt[k];
+      if (k < w) before += n;
+      total += n;
+    }
+    if (flag) {
+      lg[before + prefix] = g;
+      lci[before + prefix] = ci;
+      loff[before + prefix] = off;
+    }
+    count += total;
+    __syncthreads();
   }
-  const int hit = __syncthreads_or(any ? 1 : 0);
-  if (!hit) return;
-  for (int c = threadIdx.x; c < E; c += blockDim.x) {
-    const float v = (part[c] + part[E + c]) + (part[2 * E + c] + part[3 * E + c]);
-    atomicAdd(dtable + id * E + c, v);
+  if (count == 0) return;
+  if (tid < 4) {                                        // pad the list to a multiple of four with null entries
+    lg[count + tid] = 0.f;
+    lci[count + tid] = 0;
+    loff[count + tid] = 0;
+  }
+  __syncthreads();
+  for (int c = tid; c < E; c += 256) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int i = 0; i < count; i += 4) {
+      const float w0 = cv.wp[lci[i]][loff[i] + c];
+      const float w1 = cv.wp[lci[i + 1]][loff[i + 1] + c];
+      const float w2 = cv.wp[lci[i + 2]][loff[i + 2] + c];
+      const float w3 = cv.wp[lci[i + 3]][loff[i + 3] + c];
+      a0 = fmaf(lg[i], w0, a0);
+      a1 = fmaf(lg[i + 1], w1, a1);
+      a2 = fmaf(lg[i + 2], w2, a2);
+      a3 = fmaf(lg[i + 3], w3, a3);
+    }
+    atomicAdd(dtable + id * E + c, (a0 + a1) + (a2 + a3));
   }
 }
 
@@ -216,7 +242,7 @@ MMSA_EXPORT int mmsa_text_bwd(const float* dfeat, const float* feat, const int* 
       default: return MMSA_ERR_ARG;
     }
   }
-  const size_t shmem = ((size_t)2 * nconv * F + (size_t)4 * E) * sizeof(float);
+  const size_t shmem = (size_t)3 * (nconv * F + 4) * sizeof(float);
   MMSA_REQUIRE(shmem <= 48 * 1024);
   hipLaunchKernelGGL(text_bwd_emb_kernel, dim3(L, B), dim3(256), shmem, s, dfeat, feat, arg, ids, cv, dtable, L, E, F,
                      ldf, padding_idx);

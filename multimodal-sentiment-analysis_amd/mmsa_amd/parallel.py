@@ -1,0 +1,73 @@
+"""Data-parallel host logic (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" on CPU).
+
+The reference is single-process; sharding follows its data conventions: training batches are drawn from a seeded
+permutation with ``drop_last`` (`CNN implementation/multimodal_train.py:435-442`), test sets are walked in order
+(`multimodal_test.py:194-212`).  Utterances are independent, so the only exchange per training step is the sum
+of the flat gradient buffer; inference exchanges nothing but the final predictions.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world_info(group=None) -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def make_buckets(n: int, bucket_elems: int) -> List[Tuple[int, int]]:
+    """Contiguous [lo, hi) slices of a flat buffer of n elements, each at most bucket_elems long."""
+    bucket_elems = max(int(bucket_elems), 1)
+    return [(i, min(n, i + bucket_elems)) for i in range(0, n, bucket_elems)]
+
+
+def allreduce_buckets(flat: torch.Tensor, buckets, group=None, async_op: bool = False):
+    """Sum ``flat`` over ranks, one all-reduce per bucket (in place).  Returns the work handles when async."""
+    handles = []
+    for lo, hi in buckets:
+        h = dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if async_op:
+            handles.append(h)
+    return handles
+
+
+def train_batches(n_items: int, per_rank_batch: int, epoch_seed: int, rank: int, world: int):
+    """Index batches for one epoch: a seeded permutation cut into global batches of ``world * per_rank_batch``
+    (incomplete tail dropped, as ``drop_last=True``); rank r takes positions ``r::world`` of each global batch."""
+    g = torch.Generator().manual_seed(int(epoch_seed))
+    perm = torch.randperm(n_items, generator=g)
+    gb = world * per_rank_batch
+    out = []
+    for s in range(0, n_items - gb + 1, gb):
+        out.append(perm[s:s + gb][rank::world].clone())
+    return out
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous inference shard [lo, hi): ceil(n/world) items per rank, the last ranks may get fewer or none."""
+    per = (n_items + world - 1) // world
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per)
+
+
+def gather_predictions(probs: torch.Tensor, preds: torch.Tensor, n_items: int, group=None):
+    """All-gather per-rank ``probs [n_r, C]`` / ``preds [n_r]`` (shards from :func:`shard_range`) back into dataset
+    order on every rank.  Shards are padded to equal length for the collective and trimmed afterwards."""
+    rank, world = world_info(group)
+    if world == 1:
+        return probs, preds
+    per = (n_items + world - 1) // world
+    C = probs.shape[1]
+    pp = probs.new_zeros((per, C))
+    pr = preds.new_zeros((per,))
+    pp[:probs.shape[0]] = probs
+    pr[:preds.shape[0]] = preds
+    all_p = [torch.empty_like(pp) for _ in range(world)]
+    all_r = [torch.empty_like(pr) for _ in range(world)]
+    dist.all_gather(all_p, pp, group=group)
+    dist.all_gather(all_r, pr, group=group)
+    return torch.cat(all_p)[:n_items], torch.cat(all_r)[:n_items]

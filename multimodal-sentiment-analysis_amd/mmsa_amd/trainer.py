@@ -18,7 +18,7 @@ from typing import Optional
 
 import torch
 
-from . import ops
+from . import ops, parallel
 from .model import L2_LAMBDA, MultimodalSentimentModel
 from .workspace import Grads, Workspace
 
@@ -50,15 +50,15 @@ class TrainStep:
         self.pg = process_group
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             self.world = torch.distributed.get_world_size(process_group)
-        n = self.g.numel()
-        per = max(int(bucket_mb * 1024 * 1024 / 4), 1)
-        self._buckets = [(i, min(n, i + per)) for i in range(0, n, per)]
+        self._buckets = parallel.make_buckets(self.g.numel(), int(bucket_mb * 1024 * 1024 / 4))
         if use_graph and model.training and model._drop_p() > 0:
             raise ValueError("graph replay would repeat the same dropout masks every step; use use_graph=False "
                              "when dropout is active")
 
     # ------------------------------------------------------------------ one step's launch sequence
-    def _body(self, audio, input_ids, labels, wave):
+    def _forward_backward(self, audio, input_ids, labels, wave):
+        """Front end, forward, backward: leaves this rank's data gradient (already divided by the world size) in
+        self.g.  Pure kernel launches on the current stream: capturable."""
         model = self.model
         if wave is not None:
             audio = self.ws.buf("step.spec", (wave.shape[0], 1, 64, 130))
@@ -69,16 +69,19 @@ class TrainStep:
         if self.world > 1:
             d.mul_(1.0 / self.world)            # sum over ranks of per-rank means -> global mean
         model._backward(run, d, self.grads, self.ws)
-        if self.world > 1:
-            self._allreduce()
-        self._update(run.l2)
         self.loss = run.loss
         self.logits = run.head.logits
         self.probs = run.head.probs
+        return run.l2
+
+    def _body(self, audio, input_ids, labels, wave):
+        l2 = self._forward_backward(audio, input_ids, labels, wave)
+        if self.world > 1:
+            self._allreduce()
+        self._update(l2)
 
     def _allreduce(self):
-        for lo, hi in self._buckets:
-            torch.distributed.all_reduce(self.g[lo:hi], group=self.pg)
+        parallel.allreduce_buckets(self.g, self._buckets, self.pg)
 
     def _update(self, l2: bool):
         """Clip + AdamW over the flat buffers.  self.g holds the DATA gradient only: the regulariser's gradient
@@ -117,10 +120,12 @@ class TrainStep:
             if t is not None:
                 want = torch.int64 if k in ("input_ids", "labels") else torch.float32
                 ins[k] = t.to(device=dev, dtype=want, non_blocking=True).contiguous()
-        if not self.use_graph or self.world > 1:
+        if not self.use_graph:
             self._body(ins["audio"], ins["input_ids"], ins["labels"], ins["wave"])
             return self.loss
-        # graph mode: inputs are copied into static buffers, the captured launch sequence is replayed
+        # graph mode: inputs are copied into static buffers, the captured launch sequences are replayed.
+        # One graph holds the whole step on a single GPU; with several ranks the step is two graphs
+        # (forward+backward, clip+AdamW) with the RCCL all-reduce issued eagerly between them.
         for k, t in ins.items():
             if t is None:
                 continue
@@ -140,10 +145,23 @@ class TrainStep:
                 return self.loss
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._body(*args)
-            self._graph = g                    # capture only records: the replay below executes this step
-        self._graph.replay()
+            if self.world == 1:
+                with torch.cuda.graph(g):
+                    self._body(*args)
+                self._graph = (g, None)
+            else:
+                with torch.cuda.graph(g):
+                    l2 = self._forward_backward(*args)
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g.pool()):
+                    self._update(l2)
+                self._graph = (g, g2)
+            # capture only records: the replays below execute this step
+        g, g2 = self._graph
+        g.replay()
+        if g2 is not None:
+            self._allreduce()
+            g2.replay()
         return self.loss
 
     @torch.no_grad()
