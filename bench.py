@@ -79,7 +79,8 @@ def main():
         raise SystemExit("for --gpus > 1 launch with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ     # launched by torch.distributed.run
+    if distributed:
         torch.distributed.init_process_group("nccl", device_id=dev)
 
     from mmsa_amd import data, ops
@@ -105,7 +106,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -117,7 +118,7 @@ def main():
         loss = run(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -150,8 +151,6 @@ def main():
                         "all_kernels": {k: {"ms_per_step": round(v[0] / args.profile_steps, 4),
                                             "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else None}
                                         for k, v in agg.items()}}
-    elif world > 1 and False:
-        pass
 
     if rank == 0:
         utt = world * PER_GPU_BATCH * args.steps
@@ -174,7 +173,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

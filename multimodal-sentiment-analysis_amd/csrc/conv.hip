@@ -26,6 +26,8 @@
 // [Cout][Cin][kh][kw] layout.
 #include "mmsa_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int MAX_TAPS = 9;
@@ -56,19 +58,20 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STATS, bool ACCUM>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int D, bool STATS, bool ACCUM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
                                                          float* __restrict__ Y, float* __restrict__ stats,
                                                          ConvGeom g, int tiles_per_img) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(D == 2 || D == 3, "prefetch depth");
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold whole 32x32 MFMA tiles");
   constexpr int A_LD = BM / 32;  // float4 loads per thread for the A tile (256 threads x 8 float4 per row)
   constexpr int B_LD = BN / 32;
+  constexpr int BUF_FLOATS = (BM + BN) * LDS_STRIDE;   // one LDS buffer: A rows then B rows of one 32-channel chunk
 
   extern __shared__ float lds[];
-  constexpr int BUF_FLOATS = (BM + BN) * LDS_STRIDE;  // one staging buffer: A rows then B rows
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -79,48 +82,59 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
   const int p0 = tile * BM;
   const int n0 = blockIdx.y * BN;
 
-  // per-thread staging coordinates
+  // Per-thread staging plan, computed once: element offset of each A row inside the image and a bit mask of the
+  // taps whose source pixel lies inside the image (so the K loop has no bounds arithmetic and no branches).
   const int c4 = t & 7;         // which float4 of the 32-channel chunk
   const int rbase = t >> 3;     // 0..31
-  int ph[A_LD], pw[A_LD];
-  bool pv[A_LD];
+  int aoff[A_LD], boff[B_LD];
+  unsigned amask[A_LD];
 #pragma unroll
   for (int j = 0; j < A_LD; ++j) {
     const int p = p0 + rbase + 32 * j;
-    pv[j] = p < HW;
-    ph[j] = p / g.W;
-    pw[j] = p - ph[j] * g.W;
+    const bool ok = p < HW;
+    const int h = p / g.W, w = p - h * g.W;
+    aoff[j] = ok ? p * g.Cin + 4 * c4 : 0;
+    unsigned m = 0;
+    for (int tp = 0; tp < g.ntaps; ++tp) {
+      const int hh = h + g.dh[tp], ww = w + g.dw[tp];
+      if (ok && hh >= 0 && hh < g.H && ww >= 0 && ww < g.W) m |= 1u << tp;
+    }
+    amask[j] = m;
   }
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) boff[j] = (n0 + rbase + 32 * j) * g.Cin + 4 * c4;
   const float* Xb = X + (long)b * HW * g.Cin;
-  const int chunks_per_tap = g.Cin / KC;
-  const int nchunks = g.ntaps * chunks_per_tap;
+  const int nchunks = g.ntaps * (g.Cin / KC);
 
-  f32x4 ra[A_LD], rb[B_LD];
-  auto load_chunk = [&](int ck) {
-    const int tap = ck / chunks_per_tap;
-    const int cin0 = (ck - tap * chunks_per_tap) * KC;
-    const int dh = g.dh[tap], dw = g.dw[tap];
+  // load cursor (uniform): which (tap, channel offset) the next global load fetches; it stops at the last chunk,
+  // so the trailing prefetches of the pipeline re-read that chunk harmlessly instead of branching
+  int ltap = 0, lcin = 0, lcount = 0;
+  f32x4 ra[D][A_LD], rb[D][B_LD];
+  auto load_next = [&](f32x4(&qa)[A_LD], f32x4(&qb)[B_LD]) {
+    const int toff = (g.dh[ltap] * g.W + g.dw[ltap]) * g.Cin + lcin;
+    const int woff = ltap * g.Cout * g.Cin + lcin;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      const int hh = ph[j] + dh, ww = pw[j] + dw;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pv[j] && hh >= 0 && hh < g.H && ww >= 0 && ww < g.W)
-        v = *reinterpret_cast<const f32x4*>(Xb + ((long)(hh * g.W + ww)) * g.Cin + cin0 + 4 * c4);
-      ra[j] = v;
+      const bool valid = (amask[j] >> ltap) & 1u;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Xb + (valid ? aoff[j] + toff : 0));
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      qa[j] = valid ? v : z;
     }
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) {
-      const int n = n0 + rbase + 32 * j;
-      rb[j] = *reinterpret_cast<const f32x4*>(Wp + ((long)tap * g.Cout + n) * g.Cin + cin0 + 4 * c4);
+    for (int j = 0; j < B_LD; ++j) qb[j] = *reinterpret_cast<const f32x4*>(Wp + woff + boff[j]);
+    if (lcount + 1 < nchunks) {   // uniform scalar bookkeeping
+      ++lcount;
+      lcin += KC;
+      if (lcin == g.Cin) { lcin = 0; ++ltap; }
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, const f32x4(&qa)[A_LD], const f32x4(&qb)[B_LD]) {
+    float* base = lds + buf * BUF_FLOATS;
 #pragma unroll
-    for (int j = 0; j < A_LD; ++j)
-      *reinterpret_cast<f32x4*>(lds + buf * BUF_FLOATS + (rbase + 32 * j) * LDS_STRIDE + 4 * c4) = ra[j];
+    for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4*>(base + (rbase + 32 * j) * LDS_STRIDE + 4 * c4) = qa[j];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j)
-      *reinterpret_cast<f32x4*>(lds + buf * BUF_FLOATS + (BM + rbase + 32 * j) * LDS_STRIDE + 4 * c4) = rb[j];
+      *reinterpret_cast<f32x4*>(base + (BM + rbase + 32 * j) * LDS_STRIDE + 4 * c4) = qb[j];
   };
 
   f32x16 acc[TM][TN];
@@ -131,14 +145,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
-
   const int li = lane & 31, lh = lane >> 5;
-  for (int ck = 0; ck < nchunks; ++ck) {
-    const int buf = ck & 1;
-    if (ck + 1 < nchunks) load_chunk(ck + 1);
+  auto compute = [&](int buf) {
     const float* Ab = lds + buf * BUF_FLOATS + (wm * WTM + li) * LDS_STRIDE + 4 * lh;
     const float* Bb = lds + buf * BUF_FLOATS + (BM + wn * WTN + li) * LDS_STRIDE + 4 * lh;
 #pragma unroll
@@ -156,8 +164,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     }
-    if (ck + 1 < nchunks) store_chunk(buf ^ 1);
-    __syncthreads();
+  };
+
+  // Pipeline: register sets 0..D-1 hold chunks ck .. ck+D-1 on their way from global memory; LDS is double
+  // buffered per chunk.  Step for chunk ck (set u = ck % D, buffer ck & 1):
+  //   issue the loads of chunk ck+D into set u (its previous content is already in LDS), run the MFMAs of chunk ck,
+  //   write chunk ck+1 (set u+1, loaded D-1 steps ago) into the other buffer, barrier.
+#pragma unroll
+  for (int u = 0; u < D; ++u) load_next(ra[u], rb[u]);
+  store_chunk(0, ra[0], rb[0]);
+  __syncthreads();
+  for (int base = 0; base < nchunks; base += D) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+      const int ck = base + u;
+      if (ck < nchunks) {   // uniform; false only in the last, partial round
+        const int buf = ck & 1;
+        load_next(ra[u], rb[u]);
+        compute(buf);
+        store_chunk(buf ^ 1, ra[(u + 1) % D], rb[(u + 1) % D]);
+        __syncthreads();
+      }
+    }
   }
 
   // epilogue: D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -271,18 +299,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
       *reinterpret_cast<f32x4*>(Ys + (long)i * 4) = v;
     }
     __syncthreads();
+    // One MFMA step covers two positions (k = lane half).  Operands of step s+1 are read from LDS before the MFMAs
+    // of step s issue, so the LDS latency hides behind the matrix pipe.  For odd W the last step's second
+    // position does not exist: its dY operand is zero and its X address is clamped.
+    const int nsteps = (g.W + 1) >> 1;
     for (int r = (NT == 1 ? q : 0); r < R; r += (NT == 1 ? 2 : 1)) {
       const float* yrow = Ys + (r * g.W) * 64 + jt * 32 + li;
       const float* xrow = Xs + ((r + 1) * WP + 1) * 32 + li;
-      for (int w0 = 0; w0 < g.W; w0 += 2) {
-        const int w = w0 + kk;
+      float dy, a[MAXT];
+      {
+        const bool v = kk < g.W;
+        const int wc = v ? kk : g.W - 1;
+        dy = v ? yrow[wc * 64] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) a[i] = xrow[wc * 32 + toff[i]];
+      }
+      for (int st = 0; st < nsteps; ++st) {
+        const int w = 2 * (st + 1) + kk;
         const bool v = w < g.W;
         const int wc = v ? w : g.W - 1;
-        const float dy = v ? yrow[wc * 64] : 0.f;
+        const float ndy = v ? yrow[wc * 64] : 0.f;
+        float na[MAXT];
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) na[i] = xrow[wc * 32 + toff[i]];
 #pragma unroll
         for (int i = 0; i < MAXT; ++i)
-          if (i < t_count)
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(xrow[wc * 32 + toff[i]], dy, acc[i], 0, 0, 0);
+          if (i < t_count) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], dy, acc[i], 0, 0, 0);
+        dy = ndy;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i) a[i] = na[i];
       }
     }
   }
@@ -350,7 +395,13 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout, int ntaps) {
   const int pairs = (Cin / 32) * (Cout / 64);
   const long slab_bytes = (long)ntaps * Cin * Cout * 4 * (ntaps == 1 ? 2 : 1);
   long max_split = 512 / pairs;                                   // about two workgroups per CU
-  const long budget = (24L << 20) / slab_bytes;                   // keep the partial slabs near 24 MiB
+  static long budget_mb = -1;                                     // MMSA_WGRAD_BUDGET_MB overrides (tuning aid)
+  if (budget_mb < 0) {
+    const char* e = getenv("MMSA_WGRAD_BUDGET_MB");
+    budget_mb = e ? atol(e) : 48;
+    if (budget_mb < 1) budget_mb = 48;
+  }
+  const long budget = (budget_mb << 20) / slab_bytes;             // cap on the partial slabs (default 48 MiB)
   if (max_split > budget) max_split = budget;
   if (max_split < 1) max_split = 1;
   if (max_split > p.nstrips) max_split = p.nstrips;
@@ -371,25 +422,51 @@ int fill_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout, int ntaps, co
   return MMSA_OK;
 }
 
-template <int BM, int BN, int WM_, int WN_>
+template <int BM, int BN, int WM_, int WN_, int D, bool STATS, bool ACCUM>
+int launch_igemm_one(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int tiles, dim3 grid,
+                     hipStream_t s) {
+  constexpr size_t shmem = 2 * (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
+  static bool attr_set = false;   // raising the dynamic-LDS limit is sticky per kernel; benign if raced
+  if (shmem > 48 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM_, WN_, D, STATS, ACCUM>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
+      return MMSA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, D, STATS, ACCUM>), grid, dim3(256), shmem, s, X, Wp, Y,
+                     stats, g, tiles);
+  return mmsa_launch_status();
+}
+
+template <int BM, int BN, int WM_, int WN_, int D>
 int launch_igemm(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int accumulate,
                  hipStream_t s) {
   const int HW = g.H * g.W;
   const int tiles = mmsa_cdiv(HW, BM);
   dim3 grid(g.B * tiles, g.Cout / BN);
-  const size_t shmem = 2 * (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
   if (stats) {
     if (accumulate) return MMSA_ERR_ARG;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, true, false>), grid, dim3(256), shmem, s, X, Wp, Y, stats,
-                       g, tiles);
-  } else if (accumulate) {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, false, true>), grid, dim3(256), shmem, s, X, Wp, Y, stats,
-                       g, tiles);
-  } else {
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, false, false>), grid, dim3(256), shmem, s, X, Wp, Y,
-                       stats, g, tiles);
+    return launch_igemm_one<BM, BN, WM_, WN_, D, true, false>(X, Wp, Y, stats, g, tiles, grid, s);
   }
-  return mmsa_launch_status();
+  if (accumulate) return launch_igemm_one<BM, BN, WM_, WN_, D, false, true>(X, Wp, Y, stats, g, tiles, grid, s);
+  return launch_igemm_one<BM, BN, WM_, WN_, D, false, false>(X, Wp, Y, stats, g, tiles, grid, s);
+}
+
+// chunks in flight between global memory and LDS; MMSA_CONV_DEPTH=2|3 overrides (tuning aid)
+int pick_depth() {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("MMSA_CONV_DEPTH");
+    forced = e ? atoi(e) : 0;
+  }
+  return forced == 2 ? 2 : 3;
+}
+
+template <int BM, int BN, int WM_, int WN_>
+int launch_igemm_bkc(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int accumulate,
+                     hipStream_t s) {
+  if (pick_depth() == 2) return launch_igemm<BM, BN, WM_, WN_, 2>(X, Wp, Y, stats, g, accumulate, s);
+  return launch_igemm<BM, BN, WM_, WN_, 3>(X, Wp, Y, stats, g, accumulate, s);
 }
 
 }  // namespace
@@ -431,10 +508,10 @@ MMSA_EXPORT int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* 
   if (Cout % 64 != 0) {
     // 32-wide output (data gradient into a 32-channel tensor): 128 x 32 tiles, 4 x 1 waves
     if (stats) return MMSA_ERR_ARG;
-    return launch_igemm<128, 32, 4, 1>(X, Wp, Y, nullptr, g, accumulate, s);
+    return launch_igemm_bkc<128, 32, 4, 1>(X, Wp, Y, nullptr, g, accumulate, s);
   }
-  if (pick_bm(B, H, W, Cout) == 128) return launch_igemm<128, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, s);
-  return launch_igemm<64, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, s);
+  if (pick_bm(B, H, W, Cout) == 128) return launch_igemm_bkc<128, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, s);
+  return launch_igemm_bkc<64, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, s);
 }
 
 MMSA_EXPORT long mmsa_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int ntaps, int* nsplit_out) {

@@ -48,7 +48,10 @@ class TrainStep:
         self.logits = None
         self.world = 1
         self.pg = process_group
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
+        # the collective path is taken whenever a process group exists (also with a single rank, which keeps the
+        # multi-rank code path testable on one GPU)
+        self.dist = torch.distributed.is_available() and torch.distributed.is_initialized()
+        if self.dist:
             self.world = torch.distributed.get_world_size(process_group)
         self._buckets = parallel.make_buckets(self.g.numel(), int(bucket_mb * 1024 * 1024 / 4))
         if use_graph and model.training and model._drop_p() > 0:
@@ -76,7 +79,7 @@ class TrainStep:
 
     def _body(self, audio, input_ids, labels, wave):
         l2 = self._forward_backward(audio, input_ids, labels, wave)
-        if self.world > 1:
+        if self.dist:
             self._allreduce()
         self._update(l2)
 
@@ -145,7 +148,7 @@ class TrainStep:
                 return self.loss
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            if self.world == 1:
+            if not self.dist:
                 with torch.cuda.graph(g):
                     self._body(*args)
                 self._graph = (g, None)
