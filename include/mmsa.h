@@ -52,12 +52,21 @@ MMSA_API int mmsa_logmel_fwd(const float* wave, long wave_stride, int n_valid, i
 /* w [Cout][Cin][ntaps] -> fwd [ntaps][Cout][Cin] and/or dgrad [ntaps][Cin][Cout] (either may be null) */
 MMSA_API int mmsa_conv_pack_weights(const float* w, float* fwd, float* dgrad, int Cout, int Cin, int ntaps,
                                     void* stream);
+/* the same for n tensors in one launch; descs is a DEVICE array of records
+ * {const float* w; float* fwd; float* dgrad; int Cout, Cin, ntaps, pad;} of mmsa_conv_pack_desc_bytes() bytes each */
+MMSA_API int mmsa_conv_pack_desc_bytes(void);
+MMSA_API int mmsa_conv_pack_weights_multi(const void* descs, int n, void* stream);
 /* tile height the forward kernel uses for this geometry; statistics rows = B * ceil(H*W / tile height) */
 MMSA_API int mmsa_conv_tile_rows(int B, int H, int W, int Cout);
 /* Y[B,H,W,Cout] (= or +=) sum_t X[b, h+dh[t], w+dw[t], :] . Wp[t][:, :]; reads outside the image are zero.
  * dh/dw are host arrays.  stats (optional): [B*tiles][2][Cout] per-tile column sums and sums of squares. */
 MMSA_API int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* stats, int B, int H, int W, int Cin,
                            int Cout, int ntaps, const int* dh_host, const int* dw_host, int accumulate, void* stream);
+/* n (<= 4) convolutions of one input in one launch (the text branch's filter widths): problem i uses Wp_host[i],
+ * the first ntaps_host[i] entries of the offset table and writes Y_host[i]; multimodal_model.py:186-188 */
+MMSA_API int mmsa_conv_fwd_multi(const float* X, const float* const* Wp_host, float* const* Y_host,
+                                 const int* ntaps_host, int n, int B, int H, int W, int Cin, int Cout,
+                                 const int* dh_host, const int* dw_host, void* stream);
 MMSA_API long mmsa_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int ntaps, int* nsplit_host);
 /* dW[Cout][Cin][ntaps] (= or +=) sum_{b,h,w<w_valid} X[b,h+dh,w+dw,cin] * dY[b,h,w,cout] */
 MMSA_API int mmsa_conv_wgrad(const float* X, const float* dY, float* dW, float* workspace, int B, int H, int W,
@@ -108,6 +117,9 @@ MMSA_API int mmsa_embedding_gather(const long long* ids, const float* table, flo
                                    int* err, void* stream);
 MMSA_API int mmsa_bias_relu_maxtime(const float* y, const float* bias, float* feat, int* arg, int B, int L, int Lout,
                                     int F, int ldf, void* stream);
+MMSA_API int mmsa_bias_relu_maxtime_multi(const float* const* y_host, const float* const* bias_host,
+                                          const int* Lout_host, int n, float* feat, int* arg, int B, int L, int F,
+                                          int ldf, void* stream);
 /* sparse backward of conv + ReLU + max over time + gather; ksize/feat_off/wp/dW/dbias are host arrays
  * (wp/dW/dbias: host arrays of device pointers); dtable is accumulated into; rows == padding_idx get nothing */
 MMSA_API int mmsa_text_bwd(const float* dfeat, const float* feat, const int* arg, const float* emb,
@@ -149,7 +161,7 @@ MMSA_API int mmsa_dropout(const float* x, float* y, long n, float drop_p, unsign
 /* ---- loss regulariser, clipping, optimiser: multimodal_model.py:456-462; multimodal_train.py:194-195,481-485. */
 MMSA_API int mmsa_param_norms(const float* p, const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
                               int nchunks, const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* tnorm,
-                              float* sum_out, void* stream);
+                              float* sum_out, int chunk_sums_ready, void* stream);
 MMSA_API int mmsa_l2_grad_add(float* g, const float* p, const float* tnorm, float lambda, const long long* chunk_off,
                               const int* chunk_len, const int* chunk_tensor, int nchunks, void* stream);
 /* state[4] = global norm of g (+ lambda * p / ||p|| per tensor when p and tnorm are given) */
@@ -160,7 +172,7 @@ MMSA_API int mmsa_grad_norm(const float* g, const float* p, const float* tnorm, 
 MMSA_API int mmsa_adamw_step(float* p, const float* g, float* m, float* v, const long long* chunk_off,
                              const int* chunk_len, const int* chunk_tensor, int nchunks, const float* tnorm,
                              float lambda, float* state, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, float max_norm, int do_clip, void* stream);
+                             float weight_decay, float max_norm, int do_clip, double* chunk_ss_new, void* stream);
 MMSA_API int mmsa_scale_by_state(float* g, long n, const float* state, int idx, void* stream);
 MMSA_API int mmsa_scalar_axpy(float* dst, const float* a, const float* b, float alpha, void* stream);
 

@@ -526,27 +526,41 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ p
 // Per-channel BN backward sums for bn2 and the shortcut BN, their affine gradients and the coefficient
 // tables of pass B:   d_c2 = P[b][c]*dz + Q[c]*c2 + R[b][c],   d_sc = Ps[c]*dz + Qs[c]*sc + Rs[c].
 // tab: P[B][C], R[B][C], then Q[C], Ps[C], Qs[C], Rs[C].
-__global__ void rb_bwd_coeff_kernel(const float* __restrict__ A, const float* __restrict__ gate,
-                                    const float* __restrict__ dg, const float* __restrict__ bsum,
-                                    const float* __restrict__ coeff2, const float* __restrict__ coeffs, int B, int C,
-                                    float hw, float* __restrict__ dgamma2, float* __restrict__ dbeta2,
-                                    float* __restrict__ dgammas, float* __restrict__ dbetas, float* __restrict__ tab,
-                                    int training) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float mean2 = coeff2[c], istd2 = coeff2[C + c], sc2 = coeff2[2 * C + c];
-  const float means = coeffs[c], istds = coeffs[C + c], scs = coeffs[2 * C + c];
-  double S1 = 0.0, S2 = 0.0, S1s = 0.0, S2s = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const float a1 = A[((long)b * 3 + 0) * C + c], a2 = A[((long)b * 3 + 1) * C + c], a3 = A[((long)b * 3 + 2) * C + c];
-    const float s = gate[(long)b * C + c], g = dg[(long)b * C + c];
-    S1 += (double)(s * a1 + g);
-    S2 += (double)(s * (a2 - mean2 * a1) * istd2 + (g / hw) * (bsum[(long)b * C + c] - hw * mean2) * istd2);
-    S1s += (double)a1;
-    S2s += (double)((a3 - means * a1) * istds);
+__global__ __launch_bounds__(256) void rb_bwd_coeff_kernel(const float* __restrict__ A, const float* __restrict__ gate,
+                                                           const float* __restrict__ dg, const float* __restrict__ bsum,
+                                                           const float* __restrict__ coeff2,
+                                                           const float* __restrict__ coeffs, int B, int C, float hw,
+                                                           float* __restrict__ dgamma2, float* __restrict__ dbeta2,
+                                                           float* __restrict__ dgammas, float* __restrict__ dbetas,
+                                                           float* __restrict__ tab, int training) {
+  // 64 channels per block (lane = channel: coalesced), the four waves split the utterances; fixed-order combine
+  __shared__ double red[4][4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const bool cv = c < C;
+  float mean2 = 0.f, istd2 = 0.f, sc2 = 0.f, means = 0.f, istds = 0.f, scs = 0.f;
+  if (cv) {
+    mean2 = coeff2[c]; istd2 = coeff2[C + c]; sc2 = coeff2[2 * C + c];
+    means = coeffs[c]; istds = coeffs[C + c]; scs = coeffs[2 * C + c];
   }
-  dgamma2[c] = (float)S2; dbeta2[c] = (float)S1;
-  dgammas[c] = (float)S2s; dbetas[c] = (float)S1s;
+  double S1 = 0.0, S2 = 0.0, S1s = 0.0, S2s = 0.0;
+  if (cv)
+    for (int b = w; b < B; b += 4) {
+      const float a1 = A[((long)b * 3 + 0) * C + c], a2 = A[((long)b * 3 + 1) * C + c];
+      const float a3 = A[((long)b * 3 + 2) * C + c];
+      const float s = gate[(long)b * C + c], g = dg[(long)b * C + c];
+      S1 += (double)(s * a1 + g);
+      S2 += (double)(s * (a2 - mean2 * a1) * istd2 + (g / hw) * (bsum[(long)b * C + c] - hw * mean2) * istd2);
+      S1s += (double)a1;
+      S2s += (double)((a3 - means * a1) * istds);
+    }
+  red[0][w][lane] = S1; red[1][w][lane] = S2; red[2][w][lane] = S1s; red[3][w][lane] = S2s;
+  __syncthreads();
+  if (!cv) return;
+  S1 = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+  S2 = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+  S1s = (red[2][0][lane] + red[2][1][lane]) + (red[2][2][lane] + red[2][3][lane]);
+  S2s = (red[3][0][lane] + red[3][1][lane]) + (red[3][2][lane] + red[3][3][lane]);
   const float n = (float)B * hw;
   // in eval mode BatchNorm is a fixed affine map: only the scale survives
   const float m1 = training ? (float)S1 / n : 0.f, m2 = training ? (float)S2 / n : 0.f;
@@ -554,11 +568,15 @@ __global__ void rb_bwd_coeff_kernel(const float* __restrict__ A, const float* __
   float* P = tab;
   float* R = tab + (long)B * C;
   float* Q = tab + 2L * B * C;
-  Q[c] = -sc2 * istd2 * m2;
-  Q[C + c] = scs;                                   // Ps
-  Q[2 * C + c] = -scs * istds * m2s;                // Qs
-  Q[3 * C + c] = -scs * m1s + scs * istds * m2s * means;   // Rs
-  for (int b = 0; b < B; ++b) {
+  if (w == 0) {
+    dgamma2[c] = (float)S2; dbeta2[c] = (float)S1;
+    dgammas[c] = (float)S2s; dbetas[c] = (float)S1s;
+    Q[c] = -sc2 * istd2 * m2;
+    Q[C + c] = scs;                                          // Ps
+    Q[2 * C + c] = -scs * istds * m2s;                       // Qs
+    Q[3 * C + c] = -scs * m1s + scs * istds * m2s * means;   // Rs
+  }
+  for (int b = w; b < B; b += 4) {
     const float s = gate[(long)b * C + c], g = dg[(long)b * C + c];
     P[(long)b * C + c] = sc2 * s;
     R[(long)b * C + c] = sc2 * (g / hw - m1) + sc2 * istd2 * m2 * mean2;
@@ -853,7 +871,7 @@ MMSA_EXPORT int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const f
                      c2, sc, coeff2, coeffs, gate, dz, partial, H, W, C, chunk, nchunks);
   hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), 0, s, partial, nchunks, coeff2, gate, hid, W1, W2, A, du, dhp,
                      dg, C, Ch);
-  hipLaunchKernelGGL(rb_bwd_coeff_kernel, dim3(mmsa_cdiv(C, 64)), dim3(64), 0, s, A, gate, dg, bsum, coeff2, coeffs, B,
+  hipLaunchKernelGGL(rb_bwd_coeff_kernel, dim3(mmsa_cdiv(C, 64)), dim3(256), 0, s, A, gate, dg, bsum, coeff2, coeffs, B,
                      C, (float)(H * W), dgamma2, dbeta2, dgammas, dbetas, tab, training);
   hipLaunchKernelGGL(se_wgrad_kernel, dim3(mmsa_cdiv(2L * C * Ch, 256)), dim3(256), 0, s, du, hid, dhp, gap, dW1, dW2,
                      B, C, Ch);

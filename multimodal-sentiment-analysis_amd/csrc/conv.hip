@@ -57,11 +57,47 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
   }
 }
 
+// The same re-layout for a whole table of weight tensors in one launch (blockIdx.y = tensor).
+struct PackDesc {
+  const float* w;
+  float* fwd;
+  float* dgrad;
+  int Cout, Cin, ntaps, pad_;
+};
+
+__global__ void pack_weights_multi_kernel(const PackDesc* __restrict__ descs) {
+  const PackDesc d = descs[blockIdx.y];
+  const long total = (long)d.Cout * d.Cin * d.ntaps;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % d.ntaps);
+    const long r = i / d.ntaps;
+    const int ci = (int)(r % d.Cin);
+    const int co = (int)(r / d.Cin);
+    const float v = d.w[i];
+    if (d.fwd) d.fwd[((long)t * d.Cout + co) * d.Cin + ci] = v;
+    if (d.dgrad) d.dgrad[((long)t * d.Cin + ci) * d.Cout + co] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
+// Several convolutions of the same input in one launch (blockIdx.z = problem): per-problem packed weights, output
+// and tap count (a prefix of the shared offset table).  Used for the text branch's three filter widths.
+struct ConvMulti {
+  int n;
+  int ntaps[4];
+  const float* Wp[4];
+  float* Y[4];
+};
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, int D, bool STATS, bool ACCUM>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict__ X, const float* __restrict__ Wp,
-                                                         float* __restrict__ Y, float* __restrict__ stats,
-                                                         ConvGeom g, int tiles_per_img) {
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict__ X, const float* __restrict__ Wp0,
+                                                         float* __restrict__ Y0, float* __restrict__ stats,
+                                                         const ConvGeom g, int tiles_per_img, const ConvMulti multi) {
+  // kernel arguments are only read (never written: a modified by-value struct would be spilled to scratch)
+  const bool many = multi.n > 0;   // uniform
+  const int ntaps = many ? multi.ntaps[blockIdx.z] : g.ntaps;
+  const float* __restrict__ Wp = many ? multi.Wp[blockIdx.z] : Wp0;
+  float* __restrict__ Y = many ? multi.Y[blockIdx.z] : Y0;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
   static_assert(D == 2 || D == 3, "prefetch depth");
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // wave tile
@@ -95,7 +131,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
     const int h = p / g.W, w = p - h * g.W;
     aoff[j] = ok ? p * g.Cin + 4 * c4 : 0;
     unsigned m = 0;
-    for (int tp = 0; tp < g.ntaps; ++tp) {
+    for (int tp = 0; tp < ntaps; ++tp) {
       const int hh = h + g.dh[tp], ww = w + g.dw[tp];
       if (ok && hh >= 0 && hh < g.H && ww >= 0 && ww < g.W) m |= 1u << tp;
     }
@@ -104,7 +140,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) boff[j] = (n0 + rbase + 32 * j) * g.Cin + 4 * c4;
   const float* Xb = X + (long)b * HW * g.Cin;
-  const int nchunks = g.ntaps * (g.Cin / KC);
+  const int nchunks = ntaps * (g.Cin / KC);
 
   // load cursor (uniform): which (tap, channel offset) the next global load fetches; it stops at the last chunk,
   // so the trailing prefetches of the pipeline re-read that chunk harmlessly instead of branching
@@ -424,7 +460,7 @@ int fill_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout, int ntaps, co
 
 template <int BM, int BN, int WM_, int WN_, int D, bool STATS, bool ACCUM>
 int launch_igemm_one(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int tiles, dim3 grid,
-                     hipStream_t s) {
+                     const ConvMulti& multi, hipStream_t s) {
   constexpr size_t shmem = 2 * (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
   static bool attr_set = false;   // raising the dynamic-LDS limit is sticky per kernel; benign if raced
   if (shmem > 48 * 1024 && !attr_set) {
@@ -434,22 +470,22 @@ int launch_igemm_one(const float* X, const float* Wp, float* Y, float* stats, co
     attr_set = true;
   }
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, D, STATS, ACCUM>), grid, dim3(256), shmem, s, X, Wp, Y,
-                     stats, g, tiles);
+                     stats, g, tiles, multi);
   return mmsa_launch_status();
 }
 
 template <int BM, int BN, int WM_, int WN_, int D>
 int launch_igemm(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int accumulate,
-                 hipStream_t s) {
+                 const ConvMulti& multi, hipStream_t s) {
   const int HW = g.H * g.W;
   const int tiles = mmsa_cdiv(HW, BM);
-  dim3 grid(g.B * tiles, g.Cout / BN);
+  dim3 grid(g.B * tiles, g.Cout / BN, multi.n > 0 ? multi.n : 1);
   if (stats) {
     if (accumulate) return MMSA_ERR_ARG;
-    return launch_igemm_one<BM, BN, WM_, WN_, D, true, false>(X, Wp, Y, stats, g, tiles, grid, s);
+    return launch_igemm_one<BM, BN, WM_, WN_, D, true, false>(X, Wp, Y, stats, g, tiles, grid, multi, s);
   }
-  if (accumulate) return launch_igemm_one<BM, BN, WM_, WN_, D, false, true>(X, Wp, Y, stats, g, tiles, grid, s);
-  return launch_igemm_one<BM, BN, WM_, WN_, D, false, false>(X, Wp, Y, stats, g, tiles, grid, s);
+  if (accumulate) return launch_igemm_one<BM, BN, WM_, WN_, D, false, true>(X, Wp, Y, stats, g, tiles, grid, multi, s);
+  return launch_igemm_one<BM, BN, WM_, WN_, D, false, false>(X, Wp, Y, stats, g, tiles, grid, multi, s);
 }
 
 // chunks in flight between global memory and LDS; MMSA_CONV_DEPTH=2|3 overrides (tuning aid)
@@ -464,9 +500,9 @@ int pick_depth() {
 
 template <int BM, int BN, int WM_, int WN_>
 int launch_igemm_bkc(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int accumulate,
-                     hipStream_t s) {
-  if (pick_depth() == 2) return launch_igemm<BM, BN, WM_, WN_, 2>(X, Wp, Y, stats, g, accumulate, s);
-  return launch_igemm<BM, BN, WM_, WN_, 3>(X, Wp, Y, stats, g, accumulate, s);
+                     const ConvMulti& multi, hipStream_t s) {
+  if (pick_depth() == 2) return launch_igemm<BM, BN, WM_, WN_, 2>(X, Wp, Y, stats, g, accumulate, multi, s);
+  return launch_igemm<BM, BN, WM_, WN_, 3>(X, Wp, Y, stats, g, accumulate, multi, s);
 }
 
 }  // namespace
@@ -508,10 +544,44 @@ MMSA_EXPORT int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* 
   if (Cout % 64 != 0) {
     // 32-wide output (data gradient into a 32-channel tensor): 128 x 32 tiles, 4 x 1 waves
     if (stats) return MMSA_ERR_ARG;
-    return launch_igemm_bkc<128, 32, 4, 1>(X, Wp, Y, nullptr, g, accumulate, s);
+    return launch_igemm_bkc<128, 32, 4, 1>(X, Wp, Y, nullptr, g, accumulate, ConvMulti{}, s);
   }
-  if (pick_bm(B, H, W, Cout) == 128) return launch_igemm_bkc<128, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, s);
-  return launch_igemm_bkc<64, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, s);
+  if (pick_bm(B, H, W, Cout) == 128)
+    return launch_igemm_bkc<128, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, ConvMulti{}, s);
+  return launch_igemm_bkc<64, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, ConvMulti{}, s);
+}
+
+// n (<= 4) convolutions of the same input X in one launch: problem i uses packed weights Wp[i] ([ntaps[i]][Cout][Cin]),
+// the first ntaps[i] entries of the shared offset table and writes Y[i] ([B,H,W,Cout]).  Wp / Y / ntaps are host arrays.
+MMSA_EXPORT int mmsa_conv_fwd_multi(const float* X, const float* const* Wp, float* const* Y, const int* ntaps, int n,
+                                    int B, int H, int W, int Cin, int Cout, const int* dh, const int* dw, void* stream) {
+  MMSA_REQUIRE(X && Wp && Y && ntaps && dh && dw && n >= 1 && n <= 4);
+  MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % KC == 0 && Cout % 64 == 0);
+  int maxt = 0;
+  ConvMulti m;
+  m.n = n;
+  for (int i = 0; i < 4; ++i) {
+    m.ntaps[i] = i < n ? ntaps[i] : 0;
+    m.Wp[i] = i < n ? Wp[i] : nullptr;
+    m.Y[i] = i < n ? Y[i] : nullptr;
+    if (i < n) {
+      MMSA_REQUIRE(ntaps[i] >= 1 && ntaps[i] <= MAX_TAPS && Wp[i] && Y[i]);
+      if (ntaps[i] > maxt) maxt = ntaps[i];
+    }
+  }
+  ConvGeom g;
+  if (fill_geom(g, B, H, W, Cin, Cout, maxt, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
+  return launch_igemm_bkc<64, 64, 2, 2>(X, m.Wp[0], m.Y[0], nullptr, g, 0, m, mmsa_stream(stream));
+}
+
+MMSA_EXPORT int mmsa_conv_pack_desc_bytes() { return (int)sizeof(PackDesc); }
+
+// descs: DEVICE array of n records {const float* w; float* fwd; float* dgrad; int Cout, Cin, ntaps, pad} (40 bytes each)
+MMSA_EXPORT int mmsa_conv_pack_weights_multi(const void* descs, int n, void* stream) {
+  MMSA_REQUIRE(descs && n > 0 && n <= 65535);
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(96, n), dim3(256), 0, mmsa_stream(stream),
+                     static_cast<const PackDesc*>(descs));
+  return mmsa_launch_status();
 }
 
 MMSA_EXPORT long mmsa_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int ntaps, int* nsplit_out) {

@@ -124,7 +124,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     const int* __restrict__ chunk_tensor,
                                                     const float* __restrict__ tnorm, float lambda,
                                                     const float* __restrict__ state, float lr, float beta1, float beta2,
-                                                    float eps, float wd) {
+                                                    float eps, float wd, double* __restrict__ chunk_ss_new) {
+  __shared__ double red[16];
+  double ss = 0.0;   // sum of squares of the UPDATED parameters of this chunk (next step's regulariser norms)
   const float clip = state[ST_CLIP], bc1 = state[ST_BC1], bc2s = state[ST_BC2S];
   const float step_size = lr / bc1;
   const float decay = 1.f - lr * wd;
@@ -151,13 +153,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       pp[k] = pk;
       mm[k] = mk;
       vv[k] = vk;
+      ss += (double)pk * (double)pk;
     }
     p4[i] = pp;
     m4[i] = mm;
     v4[i] = vv;
   }
-  for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256)
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
     adamw_update(p[off + i], g[off + i], m[off + i], v[off + i], coef, clip, decay, beta1, beta2, bc2s, eps, step_size);
+    ss += (double)p[off + i] * (double)p[off + i];
+  }
+  if (chunk_ss_new) {   // uniform
+    ss = block_sum_d(ss, red);
+    if (threadIdx.x == 0) chunk_ss_new[c] = ss;
+  }
 }
 
 __global__ void add_scaled_scalar_kernel(float* __restrict__ dst, const float* __restrict__ a,
@@ -170,12 +179,13 @@ __global__ void add_scaled_scalar_kernel(float* __restrict__ dst, const float* _
 // Per-tensor L2 norms of the flat buffer `p` -> tnorm[ntensors]; sum of norms -> state[5] (and *sum_out if given).
 MMSA_EXPORT int mmsa_param_norms(const float* p, const long long* chunk_off, const int* chunk_len,
                                  const int* chunk_tensor, int nchunks, const int* tensor_first_chunk, int ntensors,
-                                 double* chunk_ss, float* tnorm, float* sum_out, void* stream) {
+                                 double* chunk_ss, float* tnorm, float* sum_out, int chunk_sums_ready, void* stream) {
   MMSA_REQUIRE(p && chunk_off && chunk_len && chunk_tensor && tensor_first_chunk && chunk_ss && tnorm);
   MMSA_REQUIRE(nchunks > 0 && ntensors > 0 && ntensors <= 1024);
   hipStream_t s = mmsa_stream(stream);
-  hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, p, (const float*)nullptr,
-                     (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss);
+  if (!chunk_sums_ready)   // otherwise chunk_ss already holds the sums (written by the previous mmsa_adamw_step)
+    hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, p, (const float*)nullptr,
+                       (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss);
   hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors, tnorm,
                      sum_out, (float*)nullptr);
   return mmsa_launch_status();
@@ -213,12 +223,12 @@ MMSA_EXPORT int mmsa_grad_norm(const float* g, const float* p, const float* tnor
 MMSA_EXPORT int mmsa_adamw_step(float* p, const float* g, float* m, float* v, const long long* chunk_off,
                                 const int* chunk_len, const int* chunk_tensor, int nchunks, const float* tnorm,
                                 float lambda, float* state, float lr, float beta1, float beta2, float eps,
-                                float weight_decay, float max_norm, int do_clip, void* stream) {
+                                float weight_decay, float max_norm, int do_clip, double* chunk_ss_new, void* stream) {
   MMSA_REQUIRE(p && g && m && v && state && chunk_off && chunk_len && chunk_tensor && nchunks > 0);
   hipStream_t s = mmsa_stream(stream);
   hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, s, state, beta1, beta2, max_norm, do_clip);
   hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, s, p, g, m, v, chunk_off, chunk_len, chunk_tensor, tnorm,
-                     lambda, state, lr, beta1, beta2, eps, weight_decay);
+                     lambda, state, lr, beta1, beta2, eps, weight_decay, chunk_ss_new);
   return mmsa_launch_status();
 }
 

@@ -29,9 +29,24 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const long long* __res
 
 // y[b][t][f] raw conv output (row length F), valid t < Lout.  feat[b*ldf + f] = max_t relu(y + bias),
 // arg[b*ldf + f] = first t attaining it.
+struct MaxTimeMulti {
+  int n;
+  int Lout[4];
+  const float* y[4];
+  const float* bias[4];
+};
+
 __global__ void bias_relu_maxtime_kernel(const float* __restrict__ y, const float* __restrict__ bias,
                                          float* __restrict__ feat, int* __restrict__ arg, int B, int L, int Lout,
-                                         int F, int ldf) {
+                                         int F, int ldf, MaxTimeMulti multi) {
+  if (multi.n > 0) {   // uniform: problem blockIdx.z writes columns z*F .. z*F+F-1
+    const int z = blockIdx.z;
+    y = multi.y[z];
+    bias = multi.bias[z];
+    Lout = multi.Lout[z];
+    feat += z * F;
+    arg += z * F;
+  }
   // grid = (ceil(F/64), B); 64 filters per block, four thread groups scan interleaved time steps, then the
   // (value, first index) pairs are merged in LDS: larger value wins, equal values keep the earlier step.
   __shared__ float sv[4][64];
@@ -205,7 +220,26 @@ MMSA_EXPORT int mmsa_bias_relu_maxtime(const float* y, const float* bias, float*
   MMSA_REQUIRE(y && bias && feat && arg && B > 0 && L > 0 && Lout > 0 && Lout <= L && F > 0 && ldf >= F);
   MMSA_REQUIRE(B <= 65535);
   hipLaunchKernelGGL(bias_relu_maxtime_kernel, dim3(mmsa_cdiv(F, 64), B), dim3(256), 0, mmsa_stream(stream), y,
-                     bias, feat, arg, B, L, Lout, F, ldf);
+                     bias, feat, arg, B, L, Lout, F, ldf, MaxTimeMulti{});
+  return mmsa_launch_status();
+}
+
+// The same for n (<= 4) convolution outputs at once: problem i reads y[i] / bias[i] with Lout[i] valid steps and
+// writes feature columns i*F .. i*F+F-1.  y / bias / Lout are host arrays.
+MMSA_EXPORT int mmsa_bias_relu_maxtime_multi(const float* const* y, const float* const* bias, const int* Lout, int n,
+                                             float* feat, int* arg, int B, int L, int F, int ldf, void* stream) {
+  MMSA_REQUIRE(y && bias && Lout && feat && arg && n >= 1 && n <= 4 && B > 0 && B <= 65535 && L > 0 && F > 0);
+  MMSA_REQUIRE(ldf >= n * F);
+  MaxTimeMulti m;
+  m.n = n;
+  for (int i = 0; i < 4; ++i) {
+    m.y[i] = i < n ? y[i] : nullptr;
+    m.bias[i] = i < n ? bias[i] : nullptr;
+    m.Lout[i] = i < n ? Lout[i] : 0;
+    if (i < n) MMSA_REQUIRE(y[i] && bias[i] && Lout[i] > 0 && Lout[i] <= L);
+  }
+  hipLaunchKernelGGL(bias_relu_maxtime_kernel, dim3(mmsa_cdiv(F, 64), B, n), dim3(256), 0, mmsa_stream(stream), y[0],
+                     bias[0], feat, arg, B, L, Lout[0], F, ldf, m);
   return mmsa_launch_status();
 }
 

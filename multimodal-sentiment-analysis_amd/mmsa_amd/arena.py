@@ -38,7 +38,8 @@ class ChunkTable:
         self.chunk_len = torch.tensor(ln, dtype=torch.int32, device=device)
         self.chunk_tensor = torch.tensor(tid, dtype=torch.int32, device=device)
         self.tensor_first_chunk = torch.tensor(first, dtype=torch.int32, device=device)
-        self.chunk_ss = torch.zeros(self.nchunks, dtype=torch.float64, device=device)
+        self.chunk_ss = torch.zeros(self.nchunks, dtype=torch.float64, device=device)      # gradient sums
+        self.chunk_ss_p = torch.zeros(self.nchunks, dtype=torch.float64, device=device)    # parameter sums
 
 
 class ParamArena:

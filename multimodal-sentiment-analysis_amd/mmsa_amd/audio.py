@@ -20,11 +20,28 @@ def _bn_args(bn):
     return bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked
 
 
-def _pack(ws: Workspace, name: str, w: torch.Tensor, need_dgrad: bool):
+def _pack_bufs(ws: Workspace, name: str, w: torch.Tensor, need_dgrad: bool):
     f = ws.buf(name + ".wf", w.numel())
     d = ws.buf(name + ".wd", w.numel()) if need_dgrad else None
-    ops.pack_weights(w, f, d)
     return f, d
+
+
+def pack_all(m, need_grad: bool, ws: Workspace):
+    """Forward / data-gradient layouts of all seven convolution weights, re-packed in ONE launch."""
+    out, triples = {}, []
+    for i, blk in enumerate((m.res_block1, m.res_block2, m.res_block3)):
+        for tag, conv in (("c1", blk.conv1), ("c2", blk.conv2), ("sc", blk.shortcut[0])):
+            name = f"rb{i + 1}.{tag}"
+            f, d = _pack_bufs(ws, name, conv.weight, need_grad)
+            out[name] = (f, d)
+            triples.append((conv.weight, f, d))
+    plan = ws.objs.get("audio.packplan")
+    if plan is None:
+        plan = ops.PackPlan()
+        if ws.persistent:
+            ws.objs["audio.packplan"] = plan
+    plan.run(triples)
+    return out
 
 
 def _conv_bn(ws, name, X, wf, bn, B, H, W, Cin, Cout, taps, training, want_bsum):
@@ -41,12 +58,12 @@ def _conv_bn(ws, name, X, wf, bn, B, H, W, Cin, Cout, taps, training, want_bsum)
     return Y, coeff, bsum
 
 
-def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: Workspace):
+def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: Workspace, packs):
     """One ResidualBlock + the 2x2 max-pool that follows it.  a_in: [B,H,W,Cin] -> [B,H/2,W/2,Cout]."""
     s = SimpleNamespace(B=B, H=H, W=W, Cin=Cin, Cout=Cout, a_in=a_in, name=name)
-    s.w1f, s.w1d = _pack(ws, name + ".c1", blk.conv1.weight, need_grad)
-    s.w2f, s.w2d = _pack(ws, name + ".c2", blk.conv2.weight, need_grad)
-    s.wsf, s.wsd = _pack(ws, name + ".sc", blk.shortcut[0].weight, need_grad)
+    s.w1f, s.w1d = packs[name + ".c1"]
+    s.w2f, s.w2d = packs[name + ".c2"]
+    s.wsf, s.wsd = packs[name + ".sc"]
     s.c1, s.coeff1, _ = _conv_bn(ws, name + ".c1", a_in, s.w1f, blk.bn1, B, H, W, Cin, Cout, ops.TAPS3X3, training,
                                  False)
     s.h1 = ws.buf(name + ".h1", (B, H, W, Cout))
@@ -122,9 +139,10 @@ def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Works
     a = ws.buf("stem.out", (B, H // 2, W // 2, 32))
     ops.stem_apply_pool(x, conv0.weight, conv0.bias, st.coeff0, a, B, H, W)
     h, w, cin = H // 2, W // 2, 32
+    packs = pack_all(m, need_grad, ws)
     for i, blk in enumerate((m.res_block1, m.res_block2, m.res_block3)):
         cout = blk.conv1.weight.shape[0]
-        s = block_forward(blk, f"rb{i + 1}", a, B, h, w, cin, cout, training, need_grad, ws)
+        s = block_forward(blk, f"rb{i + 1}", a, B, h, w, cin, cout, training, need_grad, ws, packs)
         st.blocks.append(s)
         a, h, w, cin = s.out, h // 2, w // 2, cout
     st.P, st.C = h * w, cin

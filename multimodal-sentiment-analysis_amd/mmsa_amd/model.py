@@ -354,7 +354,7 @@ class MultimodalSentimentModel(nn.Module):
         if self.modality == "both" and (audio is None or input_ids is None):
             raise ValueError("Both audio and text inputs are required for multimodal fusion")
 
-    def _run(self, audio, input_ids, labels, drops, need_grad, ws, keep=None, logits_out=None):
+    def _run(self, audio, input_ids, labels, drops, need_grad, ws, keep=None, logits_out=None, norms_ready=False):
         """Forward launch sequence.  Returns a record with the head state, branch states and the loss buffer."""
         from types import SimpleNamespace
         arena = self._arena
@@ -383,7 +383,7 @@ class MultimodalSentimentModel(nn.Module):
         if labels is not None and self.modality == "both" and run.head.loss is not None:
             run.l2 = True
             psum = ws.buf("loss.psum", 1)
-            ops.param_norms(arena.flat, arena.table, arena.tnorm, psum)
+            ops.param_norms(arena.flat, arena.table, arena.tnorm, psum, norms_ready)
             run.loss = ws.buf("loss.total", 1)
             ops.scalar_axpy(run.loss, run.head.loss, psum, L2_LAMBDA)
         if need_grad:

@@ -89,6 +89,39 @@ def pack_weights(w: torch.Tensor, fwd: Optional[torch.Tensor], dgrad: Optional[t
     _lib.call("mmsa_conv_pack_weights", _chk(w), _opt(fwd), _opt(dgrad), cout, cin, ntaps, _stream())
 
 
+class PackPlan:
+    """A device-resident table of (weight, forward pack, data-gradient pack) triples: one launch re-packs them all.
+    The table is rebuilt only when a pointer changes (weights and workspaces are persistent in training)."""
+
+    def __init__(self):
+        self.key = None
+        self.table = None
+        self.n = 0
+
+    def run(self, triples):
+        import numpy as np
+        key = tuple((w.data_ptr(), f.data_ptr() if f is not None else 0, d.data_ptr() if d is not None else 0)
+                    for w, f, d in triples)
+        if key != self.key:
+            rec = _lib.query("mmsa_conv_pack_desc_bytes")
+            dt = np.dtype([("w", "<u8"), ("fwd", "<u8"), ("dgrad", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"),
+                           ("ntaps", "<i4"), ("pad", "<i4")])
+            if dt.itemsize != rec:
+                raise _lib.MmsaError("pack descriptor layout mismatch")
+            arr = np.zeros(len(triples), dtype=dt)
+            for i, (w, f, d) in enumerate(triples):
+                _chk(w)
+                cout, cin = w.shape[0], w.shape[1]
+                ntaps = w.numel() // (cout * cin)
+                for x in (f, d):
+                    if x is not None and (x.numel() != w.numel() or _chk(x) == 0):
+                        raise ValueError("packed buffer size mismatch")
+                arr[i] = (key[i][0], key[i][1], key[i][2], cout, cin, ntaps, 0)
+            self.table = torch.from_numpy(arr.view(np.uint8)).to(triples[0][0].device)
+            self.key, self.n = key, len(triples)
+        _lib.call("mmsa_conv_pack_weights_multi", self.table.data_ptr(), self.n, _stream())
+
+
 def conv_tile_rows(B, H, W, Cout) -> int:
     return _lib.query("mmsa_conv_tile_rows", B, H, W, Cout)
 
@@ -115,6 +148,23 @@ def conv_fwd(X, Wp, Y, stats, B, H, W, Cin, Cout, taps, negate=False, accumulate
         ev = _prof_begin(kind, 2.0 * B * H * W * Cin * Cout * len(taps))
     _lib.call("mmsa_conv_fwd", _chk(X), _chk(Wp), _chk(Y), _opt(stats), B, H, W, Cin, Cout, len(taps),
               _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), int(accumulate), _stream())
+    if ev is not None:
+        ev.record()
+
+
+def conv_fwd_multi(X, Wps, Ys, ntaps_list, B, H, W, Cin, Cout, taps):
+    """Several convolutions of X in one launch; problem i uses the first ntaps_list[i] offsets of ``taps``."""
+    if X.numel() != B * H * W * Cin or len(Wps) != len(Ys) or len(Wps) != len(ntaps_list) or len(Wps) > 4:
+        raise ValueError("conv_fwd_multi: bad arguments")
+    for wp, y, nt in zip(Wps, Ys, ntaps_list):
+        if wp.numel() != nt * Cin * Cout or y.numel() != B * H * W * Cout or nt > len(taps):
+            raise ValueError("conv_fwd_multi: operand sizes do not match the geometry")
+    ev = None
+    if PROFILE is not None:
+        ev = _prof_begin("conv_igemm_kernel<64,64,nostats,store>", 2.0 * B * H * W * Cin * Cout * sum(ntaps_list))
+    _lib.call("mmsa_conv_fwd_multi", _chk(X), _parr([_chk(w) for w in Wps]), _parr([_chk(y) for y in Ys]),
+              _iarr(ntaps_list), len(Wps), B, H, W, Cin, Cout, _iarr([t[0] for t in taps]),
+              _iarr([t[1] for t in taps]), _stream())
     if ev is not None:
         ev.record()
 
@@ -259,6 +309,14 @@ def bias_relu_maxtime(y, bias, feat, arg, B, L, Lout, F, ldf, col0):
               B, L, Lout, F, ldf, _stream())
 
 
+def bias_relu_maxtime_multi(ys, biases, louts, feat, arg, B, L, F):
+    n = len(ys)
+    if feat.shape != (B, n * F) or arg.shape != (B, n * F) or any(y.numel() != B * L * F for y in ys):
+        raise ValueError("bias_relu_maxtime_multi: bad sizes")
+    _lib.call("mmsa_bias_relu_maxtime_multi", _parr([_chk(y) for y in ys]), _parr([_chk(b) for b in biases]),
+              _iarr(louts), n, _chk(feat), _chk(arg, torch.int32), B, L, F, n * F, _stream())
+
+
 def text_bwd(dfeat, feat, arg, emb, ids, ksizes, wps, dWs, dbs, dtable, B, L, E, F, padding_idx=0):
     n = len(ksizes)
     ldf = n * F
@@ -379,10 +437,13 @@ def dropout(x, y, drop_p, seed):
 
 
 # ---------------------------------------------------------------------------------------------- optimiser
-def param_norms(flat, table, tnorm, sum_out):
+def param_norms(flat, table, tnorm, sum_out, chunk_sums_ready=False):
+    """Per-tensor norms of the flat parameter buffer.  With chunk_sums_ready the per-chunk sums of squares left in
+    ``table.chunk_ss_p`` by the previous AdamW step are used and the 38 MB pass over the parameters is skipped."""
     _lib.call("mmsa_param_norms", _chk(flat), _chk(table.chunk_off, torch.int64), _chk(table.chunk_len, torch.int32),
               _chk(table.chunk_tensor, torch.int32), table.nchunks, _chk(table.tensor_first_chunk, torch.int32),
-              table.ntensors, _chk(table.chunk_ss, torch.float64), _chk(tnorm), _opt(sum_out), _stream())
+              table.ntensors, _chk(table.chunk_ss_p, torch.float64), _chk(tnorm), _opt(sum_out),
+              int(chunk_sums_ready), _stream())
 
 
 def l2_grad_add(gflat, pflat, tnorm, lam, table):
@@ -398,14 +459,15 @@ def grad_norm(gflat, table, state, pflat=None, tnorm=None, lam=0.0):
               _chk(state), _stream())
 
 
-def adamw_step(p, g, m, v, table, state, lr, beta1, beta2, eps, wd, max_norm, do_clip, tnorm=None, lam=0.0):
+def adamw_step(p, g, m, v, table, state, lr, beta1, beta2, eps, wd, max_norm, do_clip, tnorm=None, lam=0.0,
+               emit_param_sums=False):
     n = p.numel()
     if g.numel() != n or m.numel() != n or v.numel() != n or state.numel() < 8:
         raise ValueError("adamw_step: size mismatch")
     _lib.call("mmsa_adamw_step", _chk(p), _chk(g), _chk(m), _chk(v), _chk(table.chunk_off, torch.int64),
               _chk(table.chunk_len, torch.int32), _chk(table.chunk_tensor, torch.int32), table.nchunks, _opt(tnorm),
               float(lam), _chk(state), float(lr), float(beta1), float(beta2), float(eps), float(wd), float(max_norm),
-              int(do_clip), _stream())
+              int(do_clip), _chk(table.chunk_ss_p, torch.float64) if emit_param_sums else None, _stream())
 
 
 def scale_by_state(g, state, idx):

@@ -35,14 +35,24 @@ def text_forward(m, input_ids: torch.Tensor, need_grad: bool, ws: Workspace):
     n = len(ksizes)
     st.feat = ws.buf("text.feat", (B, n * F))
     st.arg = ws.buf("text.arg", (B, n * F), torch.int32)
-    st.wps = []
-    for i, (conv, k) in enumerate(zip(m.convs, ksizes)):
-        wp = ws.buf(f"text.wp{i}", conv.weight.numel())
-        ops.pack_weights(conv.weight, wp, None)
-        st.wps.append(wp)
-        y = ws.buf(f"text.y{i}", (B, L, F))
-        ops.conv_fwd(st.emb, wp, y, None, B, 1, L, E, F, [(0, j) for j in range(k)])
-        ops.bias_relu_maxtime(y, conv.bias, st.feat, st.arg, B, L, L - k + 1, F, n * F, i * F)
+    st.wps = [ws.buf(f"text.wp{i}", conv.weight.numel()) for i, conv in enumerate(m.convs)]
+    plan = ws.objs.get("text.packplan")
+    if plan is None:
+        plan = ops.PackPlan()
+        if ws.persistent:
+            ws.objs["text.packplan"] = plan
+    plan.run([(conv.weight, wp, None) for conv, wp in zip(m.convs, st.wps)])
+    ys = [ws.buf(f"text.y{i}", (B, L, F)) for i in range(n)]
+    taps = [(0, j) for j in range(max(ksizes))]
+    if n <= 4:
+        # the filter widths share the input and differ only in tap count: one launch for all of them
+        ops.conv_fwd_multi(st.emb, st.wps, ys, ksizes, B, 1, L, E, F, taps)
+        ops.bias_relu_maxtime_multi(ys, [c.bias for c in m.convs], [L - k + 1 for k in ksizes], st.feat, st.arg,
+                                    B, L, F)
+    else:
+        for i, (conv, k) in enumerate(zip(m.convs, ksizes)):
+            ops.conv_fwd(st.emb, st.wps[i], ys[i], None, B, 1, L, E, F, taps[:k])
+            ops.bias_relu_maxtime(ys[i], conv.bias, st.feat, st.arg, B, L, L - k + 1, F, n * F, i * F)
     return st.feat, st
 
 

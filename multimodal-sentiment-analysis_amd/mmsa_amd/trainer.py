@@ -42,6 +42,8 @@ class TrainStep:
         self._keep_table = torch.tensor([[1., 1.], [0., 1.], [1., 0.], [0., 0.]], device=dev)
         self.use_graph = use_graph
         self._graph = None
+        self._norms_ready = False      # True once AdamW has left current per-chunk parameter sums behind
+        self._pversion = None
         self._static = {}
         self._warm = 0
         self.loss = None
@@ -67,7 +69,7 @@ class TrainStep:
             audio = self.ws.buf("step.spec", (wave.shape[0], 1, 64, 130))
             self.frontend(wave, out=audio)
         run = model._run(audio, input_ids, labels, None, need_grad=True, ws=self.ws,
-                         keep=(self.keep[0:1], self.keep[1:2]))
+                         keep=(self.keep[0:1], self.keep[1:2]), norms_ready=self._norms_ready)
         d = run.head.dlogits
         if self.world > 1:
             d.mul_(1.0 / self.world)            # sum over ranks of per-rank means -> global mean
@@ -94,8 +96,11 @@ class TrainStep:
         tn, lam = (a.tnorm, L2_LAMBDA) if l2 else (None, 0.0)
         if do_clip:
             ops.grad_norm(self.g, a.table, self.state, a.flat if l2 else None, tn, lam)
+        # AdamW also leaves the per-chunk sums of squares of the UPDATED parameters behind: the next step's
+        # regulariser norms need no pass of their own over the 38 MB parameter buffer
         ops.adamw_step(a.flat, self.g, self.m, self.v, a.table, self.state, self.lr, self.betas[0], self.betas[1],
-                       self.eps, self.wd, self.max_norm if do_clip else 0.0, do_clip, tn, lam)
+                       self.eps, self.wd, self.max_norm if do_clip else 0.0, do_clip, tn, lam, emit_param_sums=l2)
+        self._norms_ready = l2
 
     # ------------------------------------------------------------------ public API
     def step(self, audio=None, input_ids=None, labels=None, wave=None):
@@ -107,6 +112,16 @@ class TrainStep:
             raise ValueError("pass frontend=LogMelFrontEnd(...) to train from waveforms")
         if not model.training:
             raise RuntimeError("TrainStep.step() needs model.train()")
+        # parameter sums left by the previous step stay valid only if nobody else wrote the parameters since
+        # (load_state_dict, a user optimiser, ...): torch's version counters tell
+        pv = sum(p._version for p in self.arena.params)
+        if pv != self._pversion:
+            self._pversion = pv
+            if self._graph is None:
+                self._norms_ready = False
+            elif self._norms_ready and model.modality == "both":
+                # the captured sequence trusts the stored sums: refresh them once, outside the graph
+                ops.param_norms(self.arena.flat, self.arena.table, self.arena.tnorm, None, False)
         if model.modality == "both":
             da, dt = model.fusion_layer.draw_modality_dropout()     # host RNG, audio first, as the reference
             self.keep.copy_(self._keep_table[int(da) + 2 * int(dt)])

@@ -14,6 +14,7 @@ class Workspace:
         self.device = torch.device(device)
         self.persistent = persistent
         self._bufs: Dict[Tuple, torch.Tensor] = {}
+        self.objs: Dict[str, object] = {}      # small host-side plans (descriptor tables) that live with the buffers
 
     def buf(self, name: str, shape, dtype=torch.float32, zero: bool = False) -> torch.Tensor:
         shape = tuple(int(s) for s in (shape if isinstance(shape, (tuple, list)) else (shape,)))
