@@ -16,6 +16,48 @@ from . import ops
 from .workspace import Grads, Workspace
 
 
+_SIDE_STREAMS = {}
+
+
+def side_stream(device, which: int = 0) -> torch.cuda.Stream:
+    """Per-device helper streams.  Work that is off the critical path (weight gradients; the text branch) is
+    enqueued there between explicit fork / join points, so under-filled launches overlap instead of queueing."""
+    key = (torch.device(device).index, which)
+    s = _SIDE_STREAMS.get(key)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[key] = s
+    return s
+
+
+class fork:
+    """``with fork(ws, device) as f: ...`` runs the body on a helper stream that first waits for the current
+    stream (fork point); ``f.join()`` later makes the current stream wait for it.  Only persistent workspaces
+    fork: their buffers are never freed, so no allocator bookkeeping across streams is needed; with throw-away
+    buffers (autograd path) everything stays on one stream."""
+
+    def __init__(self, ws, device, which: int = 0):
+        self.side = side_stream(device, which) if ws.persistent else None
+        self.ctx = None
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(torch.cuda.current_stream())
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.ctx = None
+        return False
+
+    def join(self):
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
 def _bn_args(bn):
     return bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked
 
@@ -97,15 +139,19 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
     wsz = max(ops.conv_wgrad_workspace(B, H, W, Cout, Cout, 9), ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 9),
               ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 1))
     wg = ws.buf(name + ".wgrad_ws", wsz)
-    ops.conv_wgrad(s.h1, d_c2, grads.of(blk.conv2.weight), wg, B, H, W, Cout, Cout, ops.TAPS3X3)
+    # The three weight gradients feed nothing but the optimiser: they run on a helper stream while the data
+    # gradient chain (the critical path into the previous block) continues on the main stream.
+    with fork(ws, d_out.device):                 # d_c2 / d_sc are ready
+        ops.conv_wgrad(s.h1, d_c2, grads.of(blk.conv2.weight), wg, B, H, W, Cout, Cout, ops.TAPS3X3)
+        ops.conv_wgrad(s.a_in, d_sc, grads.of(blk.shortcut[0].weight), wg, B, H, W, Cin, Cout, ops.TAPS1X1)
     d_h1 = ws.buf(name + ".d_h1", (B, H, W, Cout))
     ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
     sc2 = ws.buf(name + ".bnrelu_scratch", ops.bn_relu_bwd_scratch(B * H * W, Cout))
     ops.bn_relu_bwd(d_h1, s.c1, s.coeff1, grads.of(blk.bn1.weight), grads.of(blk.bn1.bias), sc2, B * H * W, Cout,
                     training)
     d_c1 = d_h1
-    ops.conv_wgrad(s.a_in, d_c1, grads.of(blk.conv1.weight), wg, B, H, W, Cin, Cout, ops.TAPS3X3)
-    ops.conv_wgrad(s.a_in, d_sc, grads.of(blk.shortcut[0].weight), wg, B, H, W, Cin, Cout, ops.TAPS1X1)
+    with fork(ws, d_out.device):                 # d_c1 is ready
+        ops.conv_wgrad(s.a_in, d_c1, grads.of(blk.conv1.weight), wg, B, H, W, Cin, Cout, ops.TAPS3X3)
     if not need_dx:
         return None
     d_in = ws.buf(name + ".d_in", (B, H, W, Cin))
@@ -161,3 +207,4 @@ def audio_backward(m, st, dfeat: torch.Tensor, training: bool, grads: Grads, ws:
     scratch = ws.buf("stem.bwd_scratch", ops.stem_bwd_scratch(B, st.H))
     ops.stem_bwd(st.x, conv0.weight, conv0.bias, st.coeff0, d, grads.of(conv0.weight), grads.of(conv0.bias),
                  grads.of(bn0.weight), grads.of(bn0.bias), scratch, B, st.H, st.W, training)
+    fork(ws, dfeat.device).join()                # all weight gradients are in

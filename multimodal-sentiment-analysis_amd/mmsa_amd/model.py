@@ -361,10 +361,17 @@ class MultimodalSentimentModel(nn.Module):
         training = self.training
         run = SimpleNamespace(audio=None, text=None, l2=False, touched=set())
         a_feat = t_feat = None
-        if self.modality in ("audio", "both"):
+        if self.modality == "both":
+            # the two branches are independent until the head: the (small) text branch runs on a helper stream
+            with audio_engine.fork(ws, arena.device, 1) as f:
+                t_feat, run.text = text_engine.text_forward(self.text_model, input_ids, need_grad, ws)
             a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, self.audio_model.training,
                                                            need_grad, ws)
-        if self.modality in ("text", "both"):
+            f.join()
+        elif self.modality == "audio":
+            a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, self.audio_model.training,
+                                                           need_grad, ws)
+        else:
             t_feat, run.text = text_engine.text_forward(self.text_model, input_ids, need_grad, ws)
         seed = self._next_seed() if training and self._drop_p() > 0 else 0
         if self.modality == "both":
@@ -394,8 +401,10 @@ class MultimodalSentimentModel(nn.Module):
         ws = ws or Workspace(dlogits.device, persistent=False)
         if self.modality == "both":
             d_a, d_t = head_engine.head_backward_both(self, run.head, dlogits, grads, ws)
-            text_engine.text_backward(self.text_model, run.text, d_t, grads)
+            with audio_engine.fork(ws, dlogits.device, 1) as f:
+                text_engine.text_backward(self.text_model, run.text, d_t, grads)
             audio_engine.audio_backward(self.audio_model, run.audio, d_a, self.audio_model.training, grads, ws)
+            f.join()
         elif self.modality == "audio":
             d_a = head_engine.head_backward_audio(self, run.head, dlogits, grads, ws)
             audio_engine.audio_backward(self.audio_model, run.audio, d_a, self.audio_model.training, grads, ws)
