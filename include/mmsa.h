@@ -36,6 +36,10 @@ extern "C" {
 #define MMSA_EPI_LN_RELU 1  /* y = relu(LayerNorm(x W^T + b))   multimodal_model.py:237-249,395-401 */
 #define MMSA_EPI_RELU_LN 2  /* y = LayerNorm(relu(x W^T + b))   multimodal_model.py:382-388          */
 #define MMSA_EPI_RELU 3     /* y = relu(x W^T + b)                                        */
+#define MMSA_EPI_LN 4       /* y = LayerNorm(x W^T + b)         Pretrained model implementations/early_fusion.py:137-138 */
+#define MMSA_EPI_TANH 5     /* y = tanh(x W^T + b)              early_fusion.py:103-104   */
+#define MMSA_EPI_SIGMOID 6  /* y = sigmoid(x W^T + b)           early_fusion.py:110-113   */
+#define MMSA_EPI_LN_GELU 7  /* y = gelu(LayerNorm(x W^T + b))   early_fusion.py:213-219   */
 
 /* ---- log-mel front end: preprocess.py:151-168 (pad/trim, MelSpectrogram, AmplitudeToDB, normalize, NaN scrub)
  *      and :111-123 (z-score, unbiased std, clamp +-6). ------------------------------------------------------- */
@@ -146,6 +150,16 @@ MMSA_API int mmsa_fusion_mix_fwd(const float* P, const float* att, float* wts, f
                                  void* stream);
 MMSA_API int mmsa_fusion_mix_bwd(const float* dfused, const float* P, const float* wts, float* dP, float* datt, int B,
                                  int Hd, void* stream);
+/* attention-fusion head of `Pretrained model implementations/early_fusion.py:127-158`:
+ * (w0,w1) = softmax(scores[b]); Wm = [M[:, :Fd]*w0 | M[:, Fd:]*w1]  (:140-152) */
+MMSA_API int mmsa_pair_attn_mix_fwd(const float* M, const float* scores, float* wts, float* Wm, int B, int Fd,
+                                    void* stream);
+MMSA_API int mmsa_pair_attn_mix_bwd(const float* dWm, const float* M, const float* wts, float* dM, float* dscores, int B,
+                                    int Fd, int accumulate, void* stream);
+/* fused = Wm[:, :Fd]*gate + Wm[:, Fd:]*(1-gate)  (:156) */
+MMSA_API int mmsa_gate_mix_fwd(const float* Wm, const float* gate, float* fused, int B, int Fd, void* stream);
+MMSA_API int mmsa_gate_mix_bwd(const float* dfused, const float* Wm, const float* gate, float* dWm, float* dgate, int B,
+                               int Fd, int accumulate, void* stream);
 /* probabilities, mean cross-entropy and d(loss)/d(logits) = (p - onehot)/B   (:449-454) */
 MMSA_API int mmsa_softmax_ce(const float* logits, const long long* labels, float* probs, float* loss, float* dlogits,
                              int B, int C, void* stream);

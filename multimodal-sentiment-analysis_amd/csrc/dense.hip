@@ -10,8 +10,20 @@
 
 namespace {
 
-enum Epilogue { EPI_NONE = 0, EPI_LN_RELU = 1, EPI_RELU_LN = 2, EPI_RELU = 3 };
+enum Epilogue {
+  EPI_NONE = 0, EPI_LN_RELU = 1, EPI_RELU_LN = 2, EPI_RELU = 3,
+  EPI_LN = 4, EPI_TANH = 5, EPI_SIGMOID = 6, EPI_LN_GELU = 7, EPI_LAST = 7
+};
 constexpr float LN_EPS = 1e-5f;
+
+__device__ __forceinline__ bool epi_has_ln(int e) {
+  return e == EPI_LN_RELU || e == EPI_RELU_LN || e == EPI_LN || e == EPI_LN_GELU;
+}
+// exact GELU (nn.GELU default): 0.5 x (1 + erf(x / sqrt 2)) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_df(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
 
 // counter-based uniform in [0,1): one 64-bit mix per element (dropout masks; not comparable with torch's RNG)
 __device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long idx) {
@@ -62,7 +74,7 @@ __global__ __launch_bounds__(256) void dense_epilogue_kernel(const float* __rest
   const int b = blockIdx.x, t = threadIdx.x;
   const float* ps = pre + (long)b * N;
   float mean = 0.f, rstd = 1.f;
-  if (epi == EPI_LN_RELU || epi == EPI_RELU_LN) {
+  if (epi_has_ln(epi)) {
     float s = 0.f;
     for (int n = t; n < N; n += 256) {
       float v = ps[n];
@@ -85,9 +97,12 @@ __global__ __launch_bounds__(256) void dense_epilogue_kernel(const float* __rest
   const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
   for (int n = t; n < N; n += 256) {
     float v = ps[n];
-    if (epi == EPI_LN_RELU) v = fmaxf(fmaf((v - mean) * rstd, gamma[n], beta[n]), 0.f);
-    else if (epi == EPI_RELU_LN) v = fmaf((fmaxf(v, 0.f) - mean) * rstd, gamma[n], beta[n]);
-    else if (epi == EPI_RELU) v = fmaxf(v, 0.f);
+    if (epi == EPI_RELU_LN) v = fmaxf(v, 0.f);
+    if (epi_has_ln(epi)) v = fmaf((v - mean) * rstd, gamma[n], beta[n]);
+    if (epi == EPI_LN_RELU || epi == EPI_RELU) v = fmaxf(v, 0.f);
+    else if (epi == EPI_LN_GELU) v = gelu_f(v);
+    else if (epi == EPI_TANH) v = tanhf(v);
+    else if (epi == EPI_SIGMOID) v = 1.0f / (1.0f + expf(-v));
     if (drop_p > 0.f) v = hash_uniform(seed, (unsigned long long)b * N + n) >= drop_p ? v * keep_scale : 0.f;
     Y[(long)b * ldy + n] = v;
   }
@@ -110,27 +125,23 @@ __global__ __launch_bounds__(256) void dense_bwd_x_kernel(const float* __restric
   const int b = blockIdx.x, t = threadIdx.x;
   const bool first = blockIdx.y == 0;
   const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+  const bool ln = epi_has_ln(epi);
   float mean = 0.f, rstd = 1.f;
-  if (epi == EPI_LN_RELU || epi == EPI_RELU_LN) {
+  if (ln) {
     mean = stats[2 * b];
     rstd = stats[2 * b + 1];
   }
-  // pass 1: through dropout and the outer activation; LN needs two row sums
+  // pass 1: through dropout and the outer activation; LayerNorm needs two row sums
   float s1 = 0.f, s2 = 0.f;
   for (int n = t; n < N; n += 256) {
     float d = dY[(long)b * ldy + n];
     if (drop_p > 0.f) d = hash_uniform(seed, (unsigned long long)b * N + n) >= drop_p ? d * keep_scale : 0.f;
     const float p = epi == EPI_NONE ? 0.f : pre[(long)b * N + n];   // pre is null for plain linear layers
-    if (epi == EPI_LN_RELU) {
-      const float xh = (p - mean) * rstd;
-      if (fmaf(xh, gamma[n], beta[n]) <= 0.f) d = 0.f;
-      if (dLn && first) dLn[(long)b * N + n] = d;
-      const float dg = d * gamma[n];
-      g[n] = dg;
-      s1 += dg;
-      s2 = fmaf(dg, xh, s2);
-    } else if (epi == EPI_RELU_LN) {
-      const float xh = (fmaxf(p, 0.f) - mean) * rstd;
+    if (ln) {
+      const float xh = ((epi == EPI_RELU_LN ? fmaxf(p, 0.f) : p) - mean) * rstd;
+      const float y = fmaf(xh, gamma[n], beta[n]);                  // LayerNorm output
+      if (epi == EPI_LN_RELU) d = y > 0.f ? d : 0.f;
+      else if (epi == EPI_LN_GELU) d *= gelu_df(y);
       if (dLn && first) dLn[(long)b * N + n] = d;
       const float dg = d * gamma[n];
       g[n] = dg;
@@ -138,11 +149,17 @@ __global__ __launch_bounds__(256) void dense_bwd_x_kernel(const float* __restric
       s2 = fmaf(dg, xh, s2);
     } else if (epi == EPI_RELU) {
       g[n] = p > 0.f ? d : 0.f;
+    } else if (epi == EPI_TANH) {
+      const float th = tanhf(p);
+      g[n] = d * (1.f - th * th);
+    } else if (epi == EPI_SIGMOID) {
+      const float sg = 1.0f / (1.0f + expf(-p));
+      g[n] = d * sg * (1.f - sg);
     } else {
       g[n] = d;
     }
   }
-  if (epi == EPI_LN_RELU || epi == EPI_RELU_LN) {
+  if (ln) {
     s1 = block_sum(s1, red) / (float)N;
     s2 = block_sum(s2, red) / (float)N;
     for (int n = t; n < N; n += 256) {
@@ -435,14 +452,85 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
     y[i] = hash_uniform(seed, (unsigned long long)i) >= drop_p ? x[i] * keep_scale : 0.f;
 }
 
+// ---- attention fusion of two projected modalities (config "attention-fusion head") -------------------------
+// M = [text_proj | audio_proj] rows of 2*Fd, scores [B][2]: (w0,w1) = softmax(scores[b]);
+// Wm = [text_proj*w0 | audio_proj*w1] (the "combined" vector the gate reads).
+__global__ void pair_attn_mix_fwd_kernel(const float* __restrict__ M, const float* __restrict__ scores,
+                                         float* __restrict__ wts, float* __restrict__ Wm, int B, int Fd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Fd) return;
+  const int b = i / Fd, n = i - b * Fd;
+  const float a0 = scores[2 * b], a1 = scores[2 * b + 1];
+  const float m = fmaxf(a0, a1);
+  const float e0 = expf(a0 - m), e1 = expf(a1 - m);
+  const float w0 = e0 / (e0 + e1), w1 = e1 / (e0 + e1);
+  if (n == 0) { wts[2 * b] = w0; wts[2 * b + 1] = w1; }
+  Wm[(long)b * 2 * Fd + n] = M[(long)b * 2 * Fd + n] * w0;
+  Wm[(long)b * 2 * Fd + Fd + n] = M[(long)b * 2 * Fd + Fd + n] * w1;
+}
+
+// fused = wt*gate + wa*(1-gate)
+__global__ void gate_mix_fwd_kernel(const float* __restrict__ Wm, const float* __restrict__ gate,
+                                    float* __restrict__ fused, int B, int Fd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Fd) return;
+  const int b = i / Fd, n = i - b * Fd;
+  const float g = gate[i];
+  fused[i] = Wm[(long)b * 2 * Fd + n] * g + Wm[(long)b * 2 * Fd + Fd + n] * (1.f - g);
+}
+
+// dfused -> dWm (= [dfused*gate | dfused*(1-gate)], accumulated on top of what the gate's Linear sent back when
+// accumulate != 0) and dgate = dfused * (wt - wa)
+__global__ void gate_mix_bwd_kernel(const float* __restrict__ dfused, const float* __restrict__ Wm,
+                                    const float* __restrict__ gate, float* __restrict__ dWm, float* __restrict__ dgate,
+                                    int B, int Fd, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * Fd) return;
+  const int b = i / Fd, n = i - b * Fd;
+  const float d = dfused[i], g = gate[i];
+  const long o = (long)b * 2 * Fd + n;
+  if (dgate) dgate[i] = d * (Wm[o] - Wm[o + Fd]);
+  if (dWm) {
+    const float t0 = d * g, t1 = d * (1.f - g);
+    dWm[o] = accumulate ? dWm[o] + t0 : t0;
+    dWm[o + Fd] = accumulate ? dWm[o + Fd] + t1 : t1;
+  }
+}
+
+// dWm -> dM (+= when accumulate) and dscores (softmax backward); one block per utterance
+__global__ __launch_bounds__(256) void pair_attn_mix_bwd_kernel(const float* __restrict__ dWm, const float* __restrict__ M,
+                                                                const float* __restrict__ wts, float* __restrict__ dM,
+                                                                float* __restrict__ dscores, int Fd, int accumulate) {
+  __shared__ float red[16];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float w0 = wts[2 * b], w1 = wts[2 * b + 1];
+  float d0 = 0.f, d1 = 0.f;
+  for (int n = t; n < Fd; n += 256) {
+    const long o = (long)b * 2 * Fd + n;
+    const float g0 = dWm[o], g1 = dWm[o + Fd];
+    d0 = fmaf(g0, M[o], d0);
+    d1 = fmaf(g1, M[o + Fd], d1);
+    dM[o] = accumulate ? dM[o] + g0 * w0 : g0 * w0;
+    dM[o + Fd] = accumulate ? dM[o + Fd] + g1 * w1 : g1 * w1;
+  }
+  d0 = block_sum(d0, red);
+  d1 = block_sum(d1, red);
+  if (t == 0) {
+    const float dot = w0 * d0 + w1 * d1;
+    dscores[2 * b] = w0 * (d0 - dot);
+    dscores[2 * b + 1] = w1 * (d1 - dot);
+  }
+}
+
 }  // namespace
 
 MMSA_EXPORT int mmsa_dense_fwd(const float* X, int ldx, const float* W, const float* bias, const float* gamma,
                                const float* beta, float* Y, int ldy, float* pre, float* stats, int B, int K, int N,
                                int epilogue, float drop_p, unsigned long long seed, void* stream) {
   MMSA_REQUIRE(X && W && Y && B > 0 && B <= 65535 && K > 0 && N > 0 && ldx >= K && ldy >= N && K <= 12 * 1024);
-  MMSA_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_RELU && drop_p >= 0.f && drop_p < 1.f);
-  if (epilogue == EPI_LN_RELU || epilogue == EPI_RELU_LN) MMSA_REQUIRE(gamma && beta && stats);
+  MMSA_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_LAST && drop_p >= 0.f && drop_p < 1.f);
+  const bool has_ln = epilogue == EPI_LN_RELU || epilogue == EPI_RELU_LN || epilogue == EPI_LN || epilogue == EPI_LN_GELU;
+  if (has_ln) MMSA_REQUIRE(gamma && beta && stats);
   hipStream_t s = mmsa_stream(stream);
   const bool plain = epilogue == EPI_NONE && drop_p == 0.f;
   if (!plain) MMSA_REQUIRE(pre != nullptr);     // the linear output is kept for the backward pass
@@ -467,10 +555,10 @@ MMSA_EXPORT int mmsa_dense_bwd(const float* dY, int ldy, const float* X, int ldx
                                int lddx, float* dW, float* db, float* dgamma, float* dbeta, int B, int K, int N,
                                int epilogue, float drop_p, unsigned long long seed, int accumulate_dx, void* stream) {
   MMSA_REQUIRE(dY && X && W && dPre && B > 0 && B <= 65535 && K > 0 && N > 0 && N <= 12 * 1024);
-  MMSA_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_RELU);
-  const bool ln = epilogue == EPI_LN_RELU || epilogue == EPI_RELU_LN;
+  MMSA_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_LAST);
+  const bool ln = epilogue == EPI_LN_RELU || epilogue == EPI_RELU_LN || epilogue == EPI_LN || epilogue == EPI_LN_GELU;
   if (ln) MMSA_REQUIRE(pre && stats && gamma && beta && dLn);
-  if (epilogue == EPI_RELU) MMSA_REQUIRE(pre != nullptr);
+  if (epilogue != EPI_NONE) MMSA_REQUIRE(pre != nullptr);
   hipStream_t s = mmsa_stream(stream);
   hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(B, dX ? mmsa_cdiv(K, 64) : 1), dim3(256), (size_t)N * sizeof(float), s, dY,
                      ldy, pre, stats, W, gamma, beta, dPre, ln ? dLn : nullptr, dX, lddx, K, N, epilogue, drop_p, seed,
@@ -556,5 +644,37 @@ MMSA_EXPORT int mmsa_dropout(const float* x, float* y, long n, float drop_p, uns
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, mmsa_stream(stream), x, y, n, drop_p, seed);
+  return mmsa_launch_status();
+}
+
+// Attention fusion of two projected modalities (`Pretrained model implementations/early_fusion.py:136-156`).
+MMSA_EXPORT int mmsa_pair_attn_mix_fwd(const float* M, const float* scores, float* wts, float* Wm, int B, int Fd,
+                                       void* stream) {
+  MMSA_REQUIRE(M && scores && wts && Wm && B > 0 && Fd > 0);
+  hipLaunchKernelGGL(pair_attn_mix_fwd_kernel, dim3(mmsa_cdiv((long)B * Fd, 256)), dim3(256), 0, mmsa_stream(stream), M,
+                     scores, wts, Wm, B, Fd);
+  return mmsa_launch_status();
+}
+
+MMSA_EXPORT int mmsa_pair_attn_mix_bwd(const float* dWm, const float* M, const float* wts, float* dM, float* dscores,
+                                       int B, int Fd, int accumulate, void* stream) {
+  MMSA_REQUIRE(dWm && M && wts && dM && dscores && B > 0 && Fd > 0);
+  hipLaunchKernelGGL(pair_attn_mix_bwd_kernel, dim3(B), dim3(256), 0, mmsa_stream(stream), dWm, M, wts, dM, dscores, Fd,
+                     accumulate);
+  return mmsa_launch_status();
+}
+
+MMSA_EXPORT int mmsa_gate_mix_fwd(const float* Wm, const float* gate, float* fused, int B, int Fd, void* stream) {
+  MMSA_REQUIRE(Wm && gate && fused && B > 0 && Fd > 0);
+  hipLaunchKernelGGL(gate_mix_fwd_kernel, dim3(mmsa_cdiv((long)B * Fd, 256)), dim3(256), 0, mmsa_stream(stream), Wm, gate,
+                     fused, B, Fd);
+  return mmsa_launch_status();
+}
+
+MMSA_EXPORT int mmsa_gate_mix_bwd(const float* dfused, const float* Wm, const float* gate, float* dWm, float* dgate,
+                                  int B, int Fd, int accumulate, void* stream) {
+  MMSA_REQUIRE(dfused && Wm && gate && (dWm || dgate) && B > 0 && Fd > 0);
+  hipLaunchKernelGGL(gate_mix_bwd_kernel, dim3(mmsa_cdiv((long)B * Fd, 256)), dim3(256), 0, mmsa_stream(stream), dfused,
+                     Wm, gate, dWm, dgate, B, Fd, accumulate);
   return mmsa_launch_status();
 }

@@ -23,7 +23,7 @@ class _Dense:
     def __init__(self, ws, name, lin, norm, epi, B, drop_p=0.0, seed=0):
         self.lin, self.norm, self.epi, self.drop_p, self.seed, self.name = lin, norm, epi, drop_p, seed, name
         self.N, self.K = lin.weight.shape
-        ln = epi in (EPI_LN_RELU, EPI_RELU_LN)
+        ln = epi in (EPI_LN_RELU, EPI_RELU_LN, ops.EPI_LN, ops.EPI_LN_GELU)
         self.pre = ws.buf(name + ".pre", (B, self.N)) if epi != EPI_NONE else None
         self.stats = ws.buf(name + ".stats", 2 * B) if ln else None
 

@@ -37,6 +37,7 @@ def _stack(spec) -> nn.Sequential:
         "bn1": lambda n: nn.BatchNorm1d(n),
         "bn2": lambda n: nn.BatchNorm2d(n),
         "relu": lambda: nn.ReLU(),
+        "gelu": lambda: nn.GELU(),
         "drop": lambda p: nn.Dropout(p),
         "flat": lambda: nn.Flatten(),
         "sigmoid": lambda: nn.Sigmoid(),

@@ -14,6 +14,7 @@ from . import _lib
 
 F32 = torch.float32
 EPI_NONE, EPI_LN_RELU, EPI_RELU_LN, EPI_RELU = 0, 1, 2, 3
+EPI_LN, EPI_TANH, EPI_SIGMOID, EPI_LN_GELU = 4, 5, 6, 7
 BN_MOMENTUM, BN_EPS = 0.1, 1e-5
 
 TAPS3X3 = [(dh, dw) for dh in (-1, 0, 1) for dw in (-1, 0, 1)]   # kernel index kh*3+kw -> offset (kh-1, kw-1)
@@ -402,6 +403,36 @@ def fusion_mix_bwd(dfused, P, wts, dP, datt):
     if dfused.shape != (B, H2 // 2) or dP.shape != (B, H2) or datt.numel() != 2 * B:
         raise ValueError("fusion_mix_bwd: bad sizes")
     _lib.call("mmsa_fusion_mix_bwd", _chk(dfused), _chk(P), _chk(wts), _chk(dP), _chk(datt), B, H2 // 2, _stream())
+
+
+def pair_attn_mix_fwd(M, scores, wts, Wm):
+    B, F2 = M.shape
+    if scores.numel() != 2 * B or wts.numel() != 2 * B or Wm.shape != (B, F2):
+        raise ValueError("pair_attn_mix_fwd: bad sizes")
+    _lib.call("mmsa_pair_attn_mix_fwd", _chk(M), _chk(scores), _chk(wts), _chk(Wm), B, F2 // 2, _stream())
+
+
+def pair_attn_mix_bwd(dWm, M, wts, dM, dscores, accumulate=False):
+    B, F2 = M.shape
+    if dWm.shape != (B, F2) or dM.shape != (B, F2) or dscores.numel() != 2 * B:
+        raise ValueError("pair_attn_mix_bwd: bad sizes")
+    _lib.call("mmsa_pair_attn_mix_bwd", _chk(dWm), _chk(M), _chk(wts), _chk(dM), _chk(dscores), B, F2 // 2,
+              int(accumulate), _stream())
+
+
+def gate_mix_fwd(Wm, gate, fused):
+    B, F2 = Wm.shape
+    if gate.shape != (B, F2 // 2) or fused.shape != (B, F2 // 2):
+        raise ValueError("gate_mix_fwd: bad sizes")
+    _lib.call("mmsa_gate_mix_fwd", _chk(Wm), _chk(gate), _chk(fused), B, F2 // 2, _stream())
+
+
+def gate_mix_bwd(dfused, Wm, gate, dWm, dgate, accumulate=False):
+    B, F2 = Wm.shape
+    if dfused.shape != (B, F2 // 2) or (dWm is not None and dWm.shape != (B, F2)):
+        raise ValueError("gate_mix_bwd: bad sizes")
+    _lib.call("mmsa_gate_mix_bwd", _chk(dfused), _chk(Wm), _chk(gate), _opt(dWm), _opt(dgate), B, F2 // 2,
+              int(accumulate), _stream())
 
 
 def softmax_ce(logits, labels, probs, loss, dlogits):
