@@ -127,7 +127,7 @@ def main():
         raise SystemExit(f"training diverged: loss {final_loss}")
 
     roofline = None
-    if rank == 0:
+    if rank == 0 and args.profile_steps > 0:
         # per-kernel timing of the dense contractions with HIP events on the launch stream (instrumented eager steps)
         ops.PROFILE = {}
         ts_prof = ts if not use_graph else TrainStep(model, frontend=fe, use_graph=False)
@@ -145,8 +145,16 @@ def main():
             kind = max(agg, key=lambda k: agg[k][0])
             ms, fl, cnt = agg[kind]
             ach = fl / (ms * 1e-3) / 1e12
+            traffic, traffic_src = None, None
+            for cand in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                if cand.endswith("pmc_traffic.json"):        # HBM bytes per launch from separate rocprofv3 --pmc passes
+                    rec = json.load(open(os.path.join(ROOT, "profiles", cand))).get(kind)
+                    if rec:
+                        traffic, traffic_src = rec["hbm_bytes_per_launch_corrected"], "profiles/" + cand
+                    break
             roofline = {"bound": "mfma", "kernel": kind, "achieved": round(ach, 2), "peak": FP32_MATRIX_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+                        "traffic_source": traffic_src, "algorithmic_flop_per_launch": round(fl / cnt),
                         "launches": cnt, "avg_launch_us": round(ms * 1e3 / cnt, 2),
                         "all_kernels": {k: {"ms_per_step": round(v[0] / args.profile_steps, 4),
                                             "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else None}

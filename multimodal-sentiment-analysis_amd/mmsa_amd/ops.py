@@ -35,6 +35,15 @@ def _prof_begin(kind: str, flops: float):
     return e
 
 
+def _igemm_name(bm, bn, stats, accum) -> str:
+    """Name of the kernel instantiation mmsa_conv_fwd launches for this tile (as rocprofv3 prints it, without spaces)."""
+    import os
+    depth = 2 if os.environ.get("MMSA_CONV_DEPTH") == "2" else 3
+    wm, wn = (4, 1) if bn == 32 else (2, 2)
+    return "conv_igemm_kernel<%d,%d,%d,%d,%d,%s,%s>" % (bm, bn, wm, wn, depth, "true" if stats else "false",
+                                                         "true" if accum else "false")
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -144,8 +153,7 @@ def conv_fwd(X, Wp, Y, stats, B, H, W, Cin, Cout, taps, negate=False, accumulate
     ev = None
     if PROFILE is not None:
         bm, bn = (128, 32) if Cout % 64 else (conv_tile_rows(B, H, W, Cout), 64)
-        kind = "conv_igemm_kernel<%d,%d,%s,%s>" % (bm, bn, "stats" if stats is not None else "nostats",
-                                                    "accum" if accumulate else "store")
+        kind = _igemm_name(bm, bn, stats is not None, accumulate)
         ev = _prof_begin(kind, 2.0 * B * H * W * Cin * Cout * len(taps))
     _lib.call("mmsa_conv_fwd", _chk(X), _chk(Wp), _chk(Y), _opt(stats), B, H, W, Cin, Cout, len(taps),
               _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), int(accumulate), _stream())
@@ -162,7 +170,7 @@ def conv_fwd_multi(X, Wps, Ys, ntaps_list, B, H, W, Cin, Cout, taps):
             raise ValueError("conv_fwd_multi: operand sizes do not match the geometry")
     ev = None
     if PROFILE is not None:
-        ev = _prof_begin("conv_igemm_kernel<64,64,nostats,store>", 2.0 * B * H * W * Cin * Cout * sum(ntaps_list))
+        ev = _prof_begin(_igemm_name(64, 64, False, False), 2.0 * B * H * W * Cin * Cout * sum(ntaps_list))
     _lib.call("mmsa_conv_fwd_multi", _chk(X), _parr([_chk(w) for w in Wps]), _parr([_chk(y) for y in Ys]),
               _iarr(ntaps_list), len(Wps), B, H, W, Cin, Cout, _iarr([t[0] for t in taps]),
               _iarr([t[1] for t in taps]), _stream())
