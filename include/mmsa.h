@@ -72,10 +72,12 @@ MMSA_API int mmsa_conv_fwd_multi(const float* X, const float* const* Wp_host, fl
                                  const int* ntaps_host, int n, int B, int H, int W, int Cin, int Cout,
                                  const int* dh_host, const int* dw_host, void* stream);
 MMSA_API long mmsa_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int ntaps, int* nsplit_host);
-/* dW[Cout][Cin][ntaps] (= or +=) sum_{b,h,w<w_valid} X[b,h+dh,w+dw,cin] * dY[b,h,w,cout] */
-MMSA_API int mmsa_conv_wgrad(const float* X, const float* dY, float* dW, float* workspace, int B, int H, int W,
-                             int w_valid, int Cin, int Cout, int ntaps, const int* dh_host, const int* dw_host,
-                             int accumulate, void* stream);
+/* dW[Cout][Cin][ntaps] (= or +=) sum_{b,h,w} X[b,h+dh,w+dw,cin] * dY[b,h,w,cout], in two launches on one stream:
+ * mmsa_conv_wgrad writes partial slabs into workspace, mmsa_conv_wgrad_reduce sums them into dW in fixed order */
+MMSA_API int mmsa_conv_wgrad(const float* X, const float* dY, float* workspace, int B, int H, int W, int w_valid,
+                             int Cin, int Cout, int ntaps, const int* dh_host, const int* dw_host, void* stream);
+MMSA_API int mmsa_conv_wgrad_reduce(const float* workspace, float* dW, int B, int H, int W, int Cin, int Cout,
+                                    int ntaps, int accumulate, void* stream);
 
 /* ---- audio branch, bandwidth-bound parts: multimodal_model.py:78-83 (stem), :27-42 (SEBlock), :64-70
  *      (ResidualBlock tail), :87-96,118-127 (pools, global average). ----------------------------------------- */
@@ -139,6 +141,10 @@ MMSA_API int mmsa_dense_bwd(const float* dY, int ldy, const float* X, int ldx, c
                             const float* W, const float* gamma, const float* beta, float* dPre, float* dLn, float* dX,
                             int lddx, float* dW, float* db, float* dgamma, float* dbeta, int B, int K, int N,
                             int epilogue, float drop_p, unsigned long long seed, int accumulate_dx, void* stream);
+/* the parameter gradients alone (after mmsa_dense_bwd was called with dW = null) */
+MMSA_API int mmsa_dense_bwd_w(const float* dPre, const float* dLn, const float* pre, const float* stats, const float* X,
+                              int ldx, float* dW, float* db, float* dgamma, float* dbeta, int B, int K, int N,
+                              int epilogue, void* stream);
 /* y = LayerNorm(x) * scale[0] * keep[0]   (keep optional: the modality-dropout switch, :264-268) */
 MMSA_API int mmsa_ln_scale_fwd(const float* x, const float* gamma, const float* beta, const float* scale,
                                const float* keep, float* y, int ldy, float* stats, int B, int N, void* stream);

@@ -600,12 +600,12 @@ MMSA_EXPORT long mmsa_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, 
   return (long)p.nslabs * ntaps * Cin * Cout;
 }
 
-// dW[Cout][Cin][ntaps] (= or +=) sum over b,h,w of X[b,h+dh,w+dw,cin] * dY[b,h,w,cout]; ntaps is 9 (offsets within
-// one pixel of the centre) or 1 (the centre), the two shapes the residual blocks need; w_valid must equal W.
-MMSA_EXPORT int mmsa_conv_wgrad(const float* X, const float* dY, float* dW, float* workspace, int B, int H, int W,
-                                int w_valid, int Cin, int Cout, int ntaps, const int* dh, const int* dw,
-                                int accumulate, void* stream) {
-  MMSA_REQUIRE(X && dY && dW && workspace && dh && dw);
+// First half of the weight gradient  dW[Cout][Cin][ntaps] = sum over b,h,w of X[b,h+dh,w+dw,cin] * dY[b,h,w,cout]:
+// partial slabs into `workspace` (mmsa_conv_wgrad_reduce finishes the job).  ntaps is 9 (offsets within one pixel of
+// the centre) or 1 (the centre), the two shapes the residual blocks need; w_valid must equal W.
+MMSA_EXPORT int mmsa_conv_wgrad(const float* X, const float* dY, float* workspace, int B, int H, int W, int w_valid,
+                                int Cin, int Cout, int ntaps, const int* dh, const int* dw, void* stream) {
+  MMSA_REQUIRE(X && dY && workspace && dh && dw);
   MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && w_valid == W);
   MMSA_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0);
   MMSA_REQUIRE(ntaps == 1 || ntaps == 9);
@@ -631,8 +631,18 @@ MMSA_EXPORT int mmsa_conv_wgrad(const float* X, const float* dY, float* dW, floa
     hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), p.shmem, s, X, dY, workspace, g, p.R, p.nstrips,
                        p.strips_per_img);
   }
+  return mmsa_launch_status();
+}
+
+// Second half of the weight gradient: sums the partial slabs mmsa_conv_wgrad left in `workspace` (fixed order) into
+// dW[Cout][Cin][ntaps] (= or +=).  Must follow mmsa_conv_wgrad with the same geometry on the same stream.
+MMSA_EXPORT int mmsa_conv_wgrad_reduce(const float* workspace, float* dW, int B, int H, int W, int Cin, int Cout,
+                                       int ntaps, int accumulate, void* stream) {
+  MMSA_REQUIRE(workspace && dW && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  MMSA_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0 && (ntaps == 1 || ntaps == 9));
+  const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, ntaps);
   const long total = (long)ntaps * Cin * Cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, workspace, dW, p.nslabs,
-                     ntaps, Cin, Cout, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, mmsa_stream(stream),
+                     workspace, dW, p.nslabs, ntaps, Cin, Cout, accumulate);
   return mmsa_launch_status();
 }

@@ -571,6 +571,21 @@ MMSA_EXPORT int mmsa_dense_bwd(const float* dY, int ldy, const float* X, int ldx
   return mmsa_launch_status();
 }
 
+// Parameter gradients of a dense layer alone, from the dPre / dLn rows a previous mmsa_dense_bwd (called with
+// dW = null) left behind: lets a caller keep these off the critical path (they feed nothing but the optimiser).
+MMSA_EXPORT int mmsa_dense_bwd_w(const float* dPre, const float* dLn, const float* pre, const float* stats,
+                                 const float* X, int ldx, float* dW, float* db, float* dgamma, float* dbeta, int B,
+                                 int K, int N, int epilogue, void* stream) {
+  MMSA_REQUIRE(dPre && X && dW && B > 0 && K > 0 && N > 0 && ldx >= K);
+  MMSA_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_LAST);
+  const bool ln = epilogue == EPI_LN_RELU || epilogue == EPI_RELU_LN || epilogue == EPI_LN || epilogue == EPI_LN_GELU;
+  if (ln) MMSA_REQUIRE(dLn && pre && stats && dgamma && dbeta);
+  const long total = (long)N * K + N;
+  hipLaunchKernelGGL(dense_bwd_w_kernel, dim3(mmsa_cdiv(total, 256)), dim3(256), 0, mmsa_stream(stream), dPre, dLn, pre,
+                     stats, X, ldx, dW, db, ln ? dgamma : nullptr, dbeta, B, K, N, epilogue);
+  return mmsa_launch_status();
+}
+
 MMSA_EXPORT int mmsa_ln_scale_fwd(const float* x, const float* gamma, const float* beta, const float* scale,
                                   const float* keep, float* y, int ldy, float* stats, int B, int N, void* stream) {
   MMSA_REQUIRE(x && gamma && beta && scale && y && stats && B > 0 && N > 0 && ldy >= N);

@@ -106,14 +106,16 @@ def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: 
     s.w1f, s.w1d = packs[name + ".c1"]
     s.w2f, s.w2d = packs[name + ".c2"]
     s.wsf, s.wsd = packs[name + ".sc"]
+    # the 1x1 shortcut only meets the main chain at the fused add: it runs beside conv1 -> bn1 -> conv2
+    with fork(ws, a_in.device) as fsc:
+        s.sc, s.coeffs, _ = _conv_bn(ws, name + ".sc", a_in, s.wsf, blk.shortcut[1], B, H, W, Cin, Cout,
+                                     ops.TAPS1X1, training, False)
     s.c1, s.coeff1, _ = _conv_bn(ws, name + ".c1", a_in, s.w1f, blk.bn1, B, H, W, Cin, Cout, ops.TAPS3X3, training,
                                  False)
     s.h1 = ws.buf(name + ".h1", (B, H, W, Cout))
     ops.bn_relu_apply(s.c1, s.coeff1, s.h1, B * H * W, Cout)
     s.c2, s.coeff2, s.bsum2 = _conv_bn(ws, name + ".c2", s.h1, s.w2f, blk.bn2, B, H, W, Cout, Cout, ops.TAPS3X3,
                                        training, True)
-    s.sc, s.coeffs, _ = _conv_bn(ws, name + ".sc", a_in, s.wsf, blk.shortcut[1], B, H, W, Cin, Cout, ops.TAPS1X1,
-                                 training, False)
     W1, W2 = blk.se.fc[0].weight, blk.se.fc[2].weight
     Ch = W1.shape[0]
     s.gap = ws.buf(name + ".gap", (B, Cout))
@@ -121,6 +123,7 @@ def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: 
     s.gate = ws.buf(name + ".gate", (B, Cout))
     ops.se_gate(s.bsum2, s.coeff2, W1, W2, H * W, s.gap, s.hid, s.gate, B, Cout)
     s.out = ws.buf(name + ".out", (B, H // 2, W // 2, Cout))
+    fsc.join()
     ops.res_gate_relu_pool(s.c2, s.sc, s.coeff2, s.coeffs, s.gate, s.out, B, H, W, Cout)
     return s
 

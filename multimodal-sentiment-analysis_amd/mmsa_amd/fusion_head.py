@@ -104,6 +104,8 @@ def fusion_backward(fl, st, dfused, grads: Grads, ws: Workspace, want_dtext=Fals
     da = ws.buf("fh.daudio", st.audio.shape) if want_daudio else None
     st.tp.bwd(ws, dM[:, :Fd], dt, grads)
     st.ap.bwd(ws, dM[:, Fd:], da, grads)
+    from .audio import fork
+    fork(ws, dfused.device, 2).join()
     return dt, da
 
 

@@ -40,11 +40,16 @@ class _Dense:
         dPre = ws.buf(self.name + ".dpre", (B, self.N))
         ln = self.norm is not None
         dLn = ws.buf(self.name + ".dln", (B, self.N)) if ln else None
+        from .audio import fork
+        # the data gradient continues the chain on this stream; the parameter gradients only feed the optimiser
+        # and go to a helper stream (joined by the caller with fork(...).join() / at the end of the step)
         ops.dense_bwd(dY, self.X, self.pre, self.stats, self.lin.weight,
                       self.norm.weight if ln else None, self.norm.bias if ln else None, dPre, dLn, dX,
-                      grads.of(self.lin.weight), grads.of(self.lin.bias),
-                      grads.of(self.norm.weight) if ln else None, grads.of(self.norm.bias) if ln else None,
-                      self.epi, self.drop_p, self.seed, accumulate_dx)
+                      None, None, None, None, self.epi, self.drop_p, self.seed, accumulate_dx)
+        with fork(ws, dY.device, 2):
+            ops.dense_bwd_w(dPre, dLn, self.X, self.pre, self.stats, grads.of(self.lin.weight),
+                            grads.of(self.lin.bias), grads.of(self.norm.weight) if ln else None,
+                            grads.of(self.norm.bias) if ln else None, self.epi)
 
 
 def _finish(st, ws, logits, labels, B, need_grad):

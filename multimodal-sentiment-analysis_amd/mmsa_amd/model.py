@@ -412,6 +412,7 @@ class MultimodalSentimentModel(nn.Module):
         else:
             d_t = head_engine.head_backward_text(self, run.head, dlogits, grads, ws)
             text_engine.text_backward(self.text_model, run.text, d_t, grads)
+        audio_engine.fork(ws, dlogits.device, 2).join()      # the head's parameter gradients (helper stream 2)
 
     # ------------------------------------------------------------------ the reference's forward signature
     def forward(self, audio=None, input_ids=None, attention_mask=None, labels=None):

@@ -188,11 +188,13 @@ def conv_wgrad(X, dY, dW, workspace, B, H, W, Cin, Cout, taps, w_valid=None, acc
     if workspace.numel() < conv_wgrad_workspace(B, H, W, Cin, Cout, len(taps)):
         raise ValueError("conv_wgrad: workspace too small")
     ev = _prof_begin("conv_wgrad_kernel<%d>" % len(taps), 2.0 * B * H * W * Cin * Cout * len(taps))
-    _lib.call("mmsa_conv_wgrad", _chk(X), _chk(dY), _chk(dW), _chk(workspace), B, H, W,
+    _lib.call("mmsa_conv_wgrad", _chk(X), _chk(dY), _chk(workspace), B, H, W,
               W if w_valid is None else w_valid, Cin, Cout, len(taps), _iarr([t[0] for t in taps]),
-              _iarr([t[1] for t in taps]), int(accumulate), _stream())
+              _iarr([t[1] for t in taps]), _stream())
     if ev is not None:
         ev.record()
+    _lib.call("mmsa_conv_wgrad_reduce", _chk(workspace), _chk(dW), B, H, W, Cin, Cout, len(taps), int(accumulate),
+              _stream())
 
 
 # ---------------------------------------------------------------------------------------------- audio branch
@@ -379,6 +381,16 @@ def dense_bwd(dY, X, pre, stats, W, gamma, beta, dPre, dLn, dX, dW, db, dgamma, 
     _lib.call("mmsa_dense_bwd", dyp, ldy, xp, ldx, _opt(pre), _opt(stats), _chk(W), _opt(gamma), _opt(beta), _chk(dPre),
               _opt(dLn), dxp, lddx, _opt(dW), _opt(db), _opt(dgamma), _opt(dbeta), B, K, N, epilogue, float(drop_p),
               int(seed), int(accumulate_dx), _stream())
+
+
+def dense_bwd_w(dPre, dLn, X, pre, stats, dW, db, dgamma, dbeta, epilogue):
+    B, K = X.shape
+    N = dW.shape[0]
+    if dPre.numel() != B * N or dW.numel() != N * K or db.numel() != N:
+        raise ValueError("dense_bwd_w: shape mismatch")
+    xp, ldx = _rows(X, "X")
+    _lib.call("mmsa_dense_bwd_w", _chk(dPre), _opt(dLn), _opt(pre), _opt(stats), xp, ldx, _chk(dW), _chk(db),
+              _opt(dgamma), _opt(dbeta), B, K, N, epilogue, _stream())
 
 
 def ln_scale_fwd(x, gamma, beta, scale, keep, y, stats):
