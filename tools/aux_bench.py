@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Secondary measurements on one MI355X: the bandwidth-bound kernels against the HBM roofline and the inference
+configuration (BASELINE config 5: --modality both, batch 1024, eval).  Prints one JSON object.
+
+    python tools/aux_bench.py
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "multimodal-sentiment-analysis_amd")):
+    sys.path.insert(0, p)
+import torch  # noqa: E402
+
+from mmsa_amd import data, ops  # noqa: E402
+from mmsa_amd.frontend import LogMelFrontEnd  # noqa: E402
+from mmsa_amd.model import MultimodalSentimentModel  # noqa: E402
+from mmsa_amd.trainer import TrainStep  # noqa: E402
+
+DEV = "cuda"
+HBM_PEAK = 8000.0  # GB/s
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e-3
+
+
+def main():
+    out = {}
+    # front end: 264 600 B in + 33 280 B out per utterance
+    fe = LogMelFrontEnd(DEV)
+    for B in (32, 1024, 4096):
+        wave = torch.randn(B, 66150, device=DEV) * 0.1
+        spec = torch.empty(B, 1, 64, 130, device=DEV)
+        t = timeit(lambda: fe(wave, out=spec))
+        gbs = B * 297880 / t / 1e9
+        out[f"frontend_B{B}"] = {"us": round(t * 1e6, 1), "utt_per_s": round(B / t), "GB_per_s": round(gbs, 1),
+                                 "frac_of_hbm_peak": round(gbs / HBM_PEAK, 4)}
+    # embedding gather: 1 KiB read + 1 KiB written per token
+    table = torch.randn(30522, 256, device=DEV)
+    for B in (32, 4096):
+        ids = torch.randint(0, 30522, (B, 128), device=DEV)
+        emb = torch.empty(B, 128, 256, device=DEV)
+        t = timeit(lambda: ops.embedding_gather(ids, table, emb, None))
+        gbs = B * 262144 / t / 1e9
+        out[f"gather_B{B}"] = {"us": round(t * 1e6, 1), "GB_per_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK, 4)}
+    # fused clip + AdamW over the 'both' parameter set: 28 B/param (+ 8 B/param for the norm pass)
+    torch.manual_seed(42)
+    model = MultimodalSentimentModel("both", audio_dropout=0.0, text_dropout=0.0, fusion_dropout=0.0).to(DEV).train()
+    ts = TrainStep(model)
+    nparam = sum(p.numel() for p in model.parameters())
+    ts.g.normal_(0, 1e-3)
+    ops.param_norms(ts.arena.flat, ts.arena.table, ts.arena.tnorm, None, False)
+    t = timeit(lambda: ts._update(True))
+    gbs = nparam * 36 / t / 1e9
+    out["clip_adamw"] = {"us": round(t * 1e6, 1), "GB_per_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK, 4),
+                         "bytes_per_param": 36}
+    # inference, config 5: eval forward of 1024 utterances (front end included), predictions stay on the device
+    model.eval()
+    b = data.make_batch(0, 64, with_wave=True)
+    wave = torch.from_numpy(b["wave"]).to(DEV).repeat(16, 1)
+    ids = torch.from_numpy(b["input_ids"]).to(DEV).repeat(16, 1)
+
+    def infer():
+        with torch.no_grad():
+            spec = fe(wave)
+            return model(audio=spec, input_ids=ids)["logits"].argmax(1)
+    t = timeit(infer, reps=5, warm=2)
+    out["inference_both_B1024"] = {"ms": round(t * 1e3, 2), "utt_per_s": round(1024 / t),
+                                   "tflops": round(1024 * 811711872 / t / 1e12, 1)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
