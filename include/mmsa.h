@@ -63,7 +63,7 @@ MMSA_API int mmsa_conv_pack_weights_multi(const void* descs, int n, void* stream
 /* tile height the forward kernel uses for this geometry; statistics rows = B * ceil(H*W / tile height) */
 MMSA_API int mmsa_conv_tile_rows(int B, int H, int W, int Cout);
 /* Y[B,H,W,Cout] (= or +=) sum_t X[b, h+dh[t], w+dw[t], :] . Wp[t][:, :]; reads outside the image are zero.
- * dh/dw are host arrays.  stats (optional): [B*tiles][2][Cout] per-tile column sums and sums of squares. */
+ * dh/dw are host arrays.  stats (optional): [2][Cout][B*tiles] per-tile column sums and sums of squares. */
 MMSA_API int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* stats, int B, int H, int W, int Cin,
                            int Cout, int ntaps, const int* dh_host, const int* dw_host, int accumulate, void* stream);
 /* n (<= 4) convolutions of one input in one launch (the text branch's filter widths): problem i uses Wp_host[i],
@@ -81,7 +81,7 @@ MMSA_API int mmsa_conv_wgrad_reduce(const float* workspace, float* dW, int B, in
 
 /* ---- audio branch, bandwidth-bound parts: multimodal_model.py:78-83 (stem), :27-42 (SEBlock), :64-70
  *      (ResidualBlock tail), :87-96,118-127 (pools, global average). ----------------------------------------- */
-/* stem Conv2d(1,32,3,pad 1,bias): per-row partial sums of the conv output, partial [B*H][2][32] */
+/* stem Conv2d(1,32,3,pad 1,bias): per-row partial sums of the conv output, partial [2][32][B*H] */
 MMSA_API int mmsa_stem_stats(const float* x, const float* w, const float* bias, float* partial, int B, int H, int W,
                              void* stream);
 /* stem conv + BN (coeff [4][32]) + ReLU + MaxPool2d(2) -> out [B][H/2][W/2][32] */

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict
     float t = 0.f;
 #pragma unroll
     for (int p = 0; p < 8; ++p) t += red[(p * 2 + which) * 32 + c];
-    partial[((long)blockIdx.x * 2 + which) * STEM_C + c] = t;
+    partial[((long)which * STEM_C + c) * gridDim.x + blockIdx.x] = t;
   }
 }
 
@@ -246,28 +246,30 @@ __global__ __launch_bounds__(1024) void stem_bwd_w_finalize_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------------------------ BatchNorm
-// partial: [rows][2][C] sums / sums of squares (rows = B * tiles, tiles of one image contiguous).
-// One wave per channel: the 64 lanes stride over the rows (independent loads), double accumulation, wave reduce.
+// partial: [2][C][rows] sums / sums of squares (rows = B * tiles, tiles of one image contiguous).
+// One workgroup per channel: the 256 threads stride over that channel's contiguous rows (coalesced), double
+// accumulation, fixed-order combination.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int tiles_per_img,
                                                           double count, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ rmean,
                                                           float* __restrict__ rvar, long long* __restrict__ nbt,
                                                           float momentum, float eps, int training,
                                                           float* __restrict__ coeff, float* __restrict__ bsum, int C) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ double red[16];
+  const int c = blockIdx.x;
   if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
-  if (c >= C) return;   // whole wave
+  const float* ps = partial + (long)c * rows;
+  const float* pq = partial + ((long)C + c) * rows;
   double s = 0.0, q = 0.0;
   if (training) {
-    for (int r = lane; r < rows; r += 64) {
-      s += (double)partial[((long)r * 2) * C + c];
-      q += (double)partial[((long)r * 2 + 1) * C + c];
+    for (int r = threadIdx.x; r < rows; r += 256) {
+      s += (double)ps[r];
+      q += (double)pq[r];
     }
-    s = wave_sum_d(s);
-    q = wave_sum_d(q);
+    s = block_sum_d(s, red);
+    q = block_sum_d(q, red + 8);
   }
-  if (lane == 0) {
+  if (threadIdx.x == 0) {
     float mean, var;
     if (training) {
       const double m = s / count;
@@ -293,9 +295,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   }
   if (bsum) {
     const int B = rows / tiles_per_img;
-    for (int b = lane; b < B; b += 64) {
+    for (int b = threadIdx.x; b < B; b += 256) {
       float t = 0.f;
-      for (int i = 0; i < tiles_per_img; ++i) t += partial[(((long)b * tiles_per_img + i) * 2) * C + c];
+      for (int i = 0; i < tiles_per_img; ++i) t += ps[(long)b * tiles_per_img + i];
       bsum[(long)b * C + c] = t;
     }
   }
@@ -784,7 +786,7 @@ MMSA_EXPORT int mmsa_bn_finalize(const float* partial, int rows, int tiles_per_i
   MMSA_REQUIRE(gamma && beta && coeff && C > 0 && rows >= 0 && tiles_per_img > 0);
   MMSA_REQUIRE(training ? (partial && count > 0) : (running_mean && running_var));
   MMSA_REQUIRE(!bsum || (partial && rows % tiles_per_img == 0));
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(mmsa_cdiv(C, 4)), dim3(256), 0, mmsa_stream(stream), partial, rows,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, mmsa_stream(stream), partial, rows,
                      tiles_per_img, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, training, coeff,
                      bsum, C);
   return mmsa_launch_status();

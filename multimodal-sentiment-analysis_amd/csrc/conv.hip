@@ -89,7 +89,7 @@ struct ConvMulti {
   float* Y[4];
 };
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int D, bool STATS, bool ACCUM>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STATS, bool ACCUM>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict__ X, const float* __restrict__ Wp0,
                                                          float* __restrict__ Y0, float* __restrict__ stats,
                                                          const ConvGeom g, int tiles_per_img, const ConvMulti multi) {
@@ -99,15 +99,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
   const float* __restrict__ Wp = many ? multi.Wp[blockIdx.z] : Wp0;
   float* __restrict__ Y = many ? multi.Y[blockIdx.z] : Y0;
   static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-  static_assert(D == 2 || D == 3, "prefetch depth");
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold whole 32x32 MFMA tiles");
-  constexpr int A_LD = BM / 32;  // float4 loads per thread for the A tile (256 threads x 8 float4 per row)
+  constexpr int A_LD = BM / 32;  // 16-byte loads per thread for the A tile (256 threads x 8 loads per row)
   constexpr int B_LD = BN / 32;
   constexpr int BUF_FLOATS = (BM + BN) * LDS_STRIDE;   // one LDS buffer: A rows then B rows of one 32-channel chunk
 
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -118,9 +117,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
   const int p0 = tile * BM;
   const int n0 = blockIdx.y * BN;
 
-  // Per-thread staging plan, computed once: element offset of each A row inside the image and a bit mask of the
-  // taps whose source pixel lies inside the image (so the K loop has no bounds arithmetic and no branches).
-  const int c4 = t & 7;         // which float4 of the 32-channel chunk
+  // Both operands are fetched through buffer descriptors: a byte offset past the end of the buffer reads as zero,
+  // which is how the taps that fall outside the image (and the rows past the end of the last tile) become zeros
+  // without any select on the loaded data (a select would force a wait for the load right where it is issued).
+  const float* Xb = X + (long)b * HW * g.Cin;
+  const __amdgpu_buffer_rsrc_t rX =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xb), 0, HW * g.Cin * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wp), 0, ntaps * g.Cout * g.Cin * 4, 0x00020000);
+  constexpr int OOB = 0x7ffffff0;
+
+  // Per-thread staging plan: byte offset of each A row inside the image and a bit mask of the taps whose source
+  // pixel lies inside the image.
+  const int c4 = t & 7;         // which 16-byte piece of the 32-channel chunk
   const int rbase = t >> 3;     // 0..31
   int aoff[A_LD], boff[B_LD];
   unsigned amask[A_LD];
@@ -129,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
     const int p = p0 + rbase + 32 * j;
     const bool ok = p < HW;
     const int h = p / g.W, w = p - h * g.W;
-    aoff[j] = ok ? p * g.Cin + 4 * c4 : 0;
+    aoff[j] = (p * g.Cin + 4 * c4) * 4;
     unsigned m = 0;
     for (int tp = 0; tp < ntaps; ++tp) {
       const int hh = h + g.dh[tp], ww = w + g.dw[tp];
@@ -138,30 +147,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
     amask[j] = m;
   }
 #pragma unroll
-  for (int j = 0; j < B_LD; ++j) boff[j] = (n0 + rbase + 32 * j) * g.Cin + 4 * c4;
-  const float* Xb = X + (long)b * HW * g.Cin;
+  for (int j = 0; j < B_LD; ++j) boff[j] = ((n0 + rbase + 32 * j) * g.Cin + 4 * c4) * 4;
   const int nchunks = ntaps * (g.Cin / KC);
 
   // load cursor (uniform): which (tap, channel offset) the next global load fetches; it stops at the last chunk,
-  // so the trailing prefetches of the pipeline re-read that chunk harmlessly instead of branching
+  // so the trailing prefetches of the pipeline re-read that chunk harmlessly instead of branching.  The tap's
+  // offset is read one chunk before it is needed (ntoff), so the scalar load is never waited for.
   int ltap = 0, lcin = 0, lcount = 0;
-  f32x4 ra[D][A_LD], rb[D][B_LD];
+  int ntoff = (g.dh[0] * g.W + g.dw[0]) * g.Cin * 4;
+  f32x4 ra[3][A_LD], rb[3][B_LD];
   auto load_next = [&](f32x4(&qa)[A_LD], f32x4(&qb)[B_LD]) {
-    const int toff = (g.dh[ltap] * g.W + g.dw[ltap]) * g.Cin + lcin;
-    const int woff = ltap * g.Cout * g.Cin + lcin;
+    const int sa = lcin * 4;
+    const int sb = (ltap * g.Cout * g.Cin + lcin) * 4;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      const bool valid = (amask[j] >> ltap) & 1u;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(Xb + (valid ? aoff[j] + toff : 0));
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      qa[j] = valid ? v : z;
+      const int va = ((amask[j] >> ltap) & 1u) ? aoff[j] + ntoff : OOB;
+      qa[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, va, sa, 0));
     }
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) qb[j] = *reinterpret_cast<const f32x4*>(Wp + woff + boff[j]);
+    for (int j = 0; j < B_LD; ++j)
+      qb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, boff[j], sb, 0));
     if (lcount + 1 < nchunks) {   // uniform scalar bookkeeping
       ++lcount;
       lcin += KC;
-      if (lcin == g.Cin) { lcin = 0; ++ltap; }
+      if (lcin == g.Cin) {
+        lcin = 0;
+        ++ltap;
+        ntoff = (g.dh[ltap] * g.W + g.dw[ltap]) * g.Cin * 4;
+      }
     }
   };
   auto store_chunk = [&](int buf, const f32x4(&qa)[A_LD], const f32x4(&qb)[B_LD]) {
@@ -181,44 +194,66 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // Fragments of half a chunk (16 of its 32 channels): lane (li, lh) holds, per 8-channel group, the 4 consecutive
+  // channels 8*gk + 4*lh .. +3 of its row and feeds them to 4 successive MFMAs; A and B use the same permutation.
   const int li = lane & 31, lh = lane >> 5;
-  auto compute = [&](int buf) {
-    const float* Ab = lds + buf * BUF_FLOATS + (wm * WTM + li) * LDS_STRIDE + 4 * lh;
-    const float* Bb = lds + buf * BUF_FLOATS + (BM + wn * WTN + li) * LDS_STRIDE + 4 * lh;
+  const int a_frag = (wm * WTM + li) * LDS_STRIDE + 4 * lh;
+  const int b_frag = (BM + wn * WTN + li) * LDS_STRIDE + 4 * lh;
+  struct Frag {
+    f32x4 a[2][TM], b[2][TN];
+  };
+  auto read_half = [&](Frag& f, int buf, int half) {
+    const float* Ab = lds + buf * BUF_FLOATS + a_frag + 16 * half;
+    const float* Bb = lds + buf * BUF_FLOATS + b_frag + 16 * half;
 #pragma unroll
-    for (int gk = 0; gk < 4; ++gk) {
-      f32x4 fa[TM], fb[TN];
+    for (int gk = 0; gk < 2; ++gk) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_STRIDE + 8 * gk);
+      for (int i = 0; i < TM; ++i) f.a[gk][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_STRIDE + 8 * gk);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_STRIDE + 8 * gk);
+      for (int j = 0; j < TN; ++j) f.b[gk][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_STRIDE + 8 * gk);
+    }
+  };
+  auto mfma_half = [&](const Frag& f) {
+#pragma unroll
+    for (int gk = 0; gk < 2; ++gk)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-    }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[gk][i][e], f.b[gk][j][e], acc[i][j], 0, 0, 0);
   };
 
-  // Pipeline: register sets 0..D-1 hold chunks ck .. ck+D-1 on their way from global memory; LDS is double
-  // buffered per chunk.  Step for chunk ck (set u = ck % D, buffer ck & 1):
-  //   issue the loads of chunk ck+D into set u (its previous content is already in LDS), run the MFMAs of chunk ck,
-  //   write chunk ck+1 (set u+1, loaded D-1 steps ago) into the other buffer, barrier.
-#pragma unroll
-  for (int u = 0; u < D; ++u) load_next(ra[u], rb[u]);
+  // Pipeline (three register sets, three LDS buffers, one barrier per chunk).  At the top of the step for chunk ck:
+  // LDS holds chunks ck and ck+1, f0 holds the fragments of the first half of chunk ck, the register sets hold
+  // chunks ck+2 and ck+3.  The step issues the global loads of chunk ck+4, reads the second-half fragments, runs the
+  // first-half MFMAs, writes chunk ck+2 to LDS, reads the first-half fragments of chunk ck+1 and runs the
+  // second-half MFMAs: every LDS read has half a chunk of matrix work between its issue and its first use, and a
+  // global load has two chunks.
+  Frag f0, f1;
+  load_next(ra[0], rb[0]);
+  load_next(ra[1], rb[1]);
+  load_next(ra[2], rb[2]);
   store_chunk(0, ra[0], rb[0]);
+  store_chunk(1, ra[1], rb[1]);
+  load_next(ra[0], rb[0]);
   __syncthreads();
-  for (int base = 0; base < nchunks; base += D) {
+  read_half(f0, 0, 0);
+  for (int base = 0; base < nchunks; base += 3) {
 #pragma unroll
-    for (int u = 0; u < D; ++u) {
-      const int ck = base + u;
-      if (ck < nchunks) {   // uniform; false only in the last, partial round
-        const int buf = ck & 1;
-        load_next(ra[u], rb[u]);
-        compute(buf);
-        store_chunk(buf ^ 1, ra[(u + 1) % D], rb[(u + 1) % D]);
+    for (int u = 0; u < 3; ++u) {
+      if (base + u < nchunks) {   // uniform; false only in the last, partial round
+        load_next(ra[(u + 1) % 3], rb[(u + 1) % 3]);
+        read_half(f1, u, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(f0);
+        __builtin_amdgcn_sched_barrier(0);
+        store_chunk((u + 2) % 3, ra[(u + 2) % 3], rb[(u + 2) % 3]);
+        read_half(f0, (u + 1) % 3, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(f1);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
       }
     }
@@ -268,8 +303,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
       float s = 0.f;
 #pragma unroll
       for (int m = 0; m < WAVES_M; ++m) s += red[(m * 2 + which) * BN + col];
-      // stats[(b*tiles + tile)][2][Cout]
-      stats[((long)blockIdx.x * 2 + which) * g.Cout + n0 + col] = s;
+      // stats[2][Cout][B*tiles]: the rows of one channel are contiguous for the kernel that sums them
+      stats[((long)which * g.Cout + n0 + col) * gridDim.x + blockIdx.x] = s;
     }
   }
 }
@@ -458,23 +493,23 @@ int fill_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout, int ntaps, co
   return MMSA_OK;
 }
 
-template <int BM, int BN, int WM_, int WN_, int D, bool STATS, bool ACCUM>
+template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM>
 int launch_igemm_one(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int tiles, dim3 grid,
                      const ConvMulti& multi, hipStream_t s) {
-  constexpr size_t shmem = 2 * (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
+  constexpr size_t shmem = 3 * (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
   static bool attr_set = false;   // raising the dynamic-LDS limit is sticky per kernel; benign if raced
   if (shmem > 48 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM_, WN_, D, STATS, ACCUM>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
       return MMSA_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, D, STATS, ACCUM>), grid, dim3(256), shmem, s, X, Wp, Y,
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM>), grid, dim3(256), shmem, s, X, Wp, Y,
                      stats, g, tiles, multi);
   return mmsa_launch_status();
 }
 
-template <int BM, int BN, int WM_, int WN_, int D>
+template <int BM, int BN, int WM_, int WN_>
 int launch_igemm(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int accumulate,
                  const ConvMulti& multi, hipStream_t s) {
   const int HW = g.H * g.W;
@@ -482,27 +517,10 @@ int launch_igemm(const float* X, const float* Wp, float* Y, float* stats, const 
   dim3 grid(g.B * tiles, g.Cout / BN, multi.n > 0 ? multi.n : 1);
   if (stats) {
     if (accumulate) return MMSA_ERR_ARG;
-    return launch_igemm_one<BM, BN, WM_, WN_, D, true, false>(X, Wp, Y, stats, g, tiles, grid, multi, s);
+    return launch_igemm_one<BM, BN, WM_, WN_, true, false>(X, Wp, Y, stats, g, tiles, grid, multi, s);
   }
-  if (accumulate) return launch_igemm_one<BM, BN, WM_, WN_, D, false, true>(X, Wp, Y, stats, g, tiles, grid, multi, s);
-  return launch_igemm_one<BM, BN, WM_, WN_, D, false, false>(X, Wp, Y, stats, g, tiles, grid, multi, s);
-}
-
-// chunks in flight between global memory and LDS; MMSA_CONV_DEPTH=2|3 overrides (tuning aid)
-int pick_depth() {
-  static int forced = -1;
-  if (forced < 0) {
-    const char* e = getenv("MMSA_CONV_DEPTH");
-    forced = e ? atoi(e) : 0;
-  }
-  return forced == 2 ? 2 : 3;
-}
-
-template <int BM, int BN, int WM_, int WN_>
-int launch_igemm_bkc(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int accumulate,
-                     const ConvMulti& multi, hipStream_t s) {
-  if (pick_depth() == 2) return launch_igemm<BM, BN, WM_, WN_, 2>(X, Wp, Y, stats, g, accumulate, multi, s);
-  return launch_igemm<BM, BN, WM_, WN_, 3>(X, Wp, Y, stats, g, accumulate, multi, s);
+  if (accumulate) return launch_igemm_one<BM, BN, WM_, WN_, false, true>(X, Wp, Y, stats, g, tiles, grid, multi, s);
+  return launch_igemm_one<BM, BN, WM_, WN_, false, false>(X, Wp, Y, stats, g, tiles, grid, multi, s);
 }
 
 }  // namespace
@@ -539,7 +557,7 @@ MMSA_EXPORT int mmsa_conv_tile_rows(int B, int H, int W, int Cout) {
 }
 
 // Y[B,H,W,Cout] = conv(X[B,H,W,Cin], Wp[ntaps][Cout][Cin]) with per-tap offsets (dh, dw); out-of-image reads are 0.
-// stats (optional): [B*ceil(H*W/BM)][2][Cout] column sums / sums of squares per tile, BM = mmsa_conv_tile_rows().
+// stats (optional): [2][Cout][B*ceil(H*W/BM)] column sums / sums of squares per tile, BM = mmsa_conv_tile_rows().
 // accumulate != 0: Y += result (stats must be null).
 MMSA_EXPORT int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* stats, int B, int H, int W, int Cin,
                               int Cout, int ntaps, const int* dh, const int* dw, int accumulate, void* stream) {
@@ -552,11 +570,11 @@ MMSA_EXPORT int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* 
   if (Cout % 64 != 0) {
     // 32-wide output (data gradient into a 32-channel tensor): 128 x 32 tiles, 4 x 1 waves
     if (stats) return MMSA_ERR_ARG;
-    return launch_igemm_bkc<128, 32, 4, 1>(X, Wp, Y, nullptr, g, accumulate, ConvMulti{}, s);
+    return launch_igemm<128, 32, 4, 1>(X, Wp, Y, nullptr, g, accumulate, ConvMulti{}, s);
   }
   if (pick_bm(B, H, W, Cout) == 128)
-    return launch_igemm_bkc<128, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, ConvMulti{}, s);
-  return launch_igemm_bkc<64, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, ConvMulti{}, s);
+    return launch_igemm<128, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, ConvMulti{}, s);
+  return launch_igemm<64, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, ConvMulti{}, s);
 }
 
 // n (<= 4) convolutions of the same input X in one launch: problem i uses packed weights Wp[i] ([ntaps[i]][Cout][Cin]),
@@ -579,7 +597,7 @@ MMSA_EXPORT int mmsa_conv_fwd_multi(const float* X, const float* const* Wp, floa
   }
   ConvGeom g;
   if (fill_geom(g, B, H, W, Cin, Cout, maxt, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
-  return launch_igemm_bkc<64, 64, 2, 2>(X, m.Wp[0], m.Y[0], nullptr, g, 0, m, mmsa_stream(stream));
+  return launch_igemm<64, 64, 2, 2>(X, m.Wp[0], m.Y[0], nullptr, g, 0, m, mmsa_stream(stream));
 }
 
 MMSA_EXPORT int mmsa_conv_pack_desc_bytes() { return (int)sizeof(PackDesc); }

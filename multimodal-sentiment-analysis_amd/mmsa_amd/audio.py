@@ -180,6 +180,9 @@ def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Works
     conv0, bn0 = m.conv1[0], m.conv1[1]
     g, b, rm, rv, nbt = _bn_args(bn0)
     st.coeff0 = ws.buf("stem.coeff", 128)
+    # the weight re-layout depends on nothing in this step: it runs beside the stem
+    with fork(ws, x.device) as fpack:
+        packs = pack_all(m, need_grad, ws)
     partial = None
     if training:
         partial = ws.buf("stem.partial", B * H * 64)
@@ -188,7 +191,7 @@ def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Works
     a = ws.buf("stem.out", (B, H // 2, W // 2, 32))
     ops.stem_apply_pool(x, conv0.weight, conv0.bias, st.coeff0, a, B, H, W)
     h, w, cin = H // 2, W // 2, 32
-    packs = pack_all(m, need_grad, ws)
+    fpack.join()
     for i, blk in enumerate((m.res_block1, m.res_block2, m.res_block3)):
         cout = blk.conv1.weight.shape[0]
         s = block_forward(blk, f"rb{i + 1}", a, B, h, w, cin, cout, training, need_grad, ws, packs)

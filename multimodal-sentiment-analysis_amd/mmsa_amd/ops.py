@@ -37,11 +37,9 @@ def _prof_begin(kind: str, flops: float):
 
 def _igemm_name(bm, bn, stats, accum) -> str:
     """Name of the kernel instantiation mmsa_conv_fwd launches for this tile (as rocprofv3 prints it, without spaces)."""
-    import os
-    depth = 2 if os.environ.get("MMSA_CONV_DEPTH") == "2" else 3
     wm, wn = (4, 1) if bn == 32 else (2, 2)
-    return "conv_igemm_kernel<%d,%d,%d,%d,%d,%s,%s>" % (bm, bn, wm, wn, depth, "true" if stats else "false",
-                                                         "true" if accum else "false")
+    return "conv_igemm_kernel<%d,%d,%d,%d,%s,%s>" % (bm, bn, wm, wn, "true" if stats else "false",
+                                                      "true" if accum else "false")
 
 
 def _stream() -> int:

@@ -108,10 +108,10 @@ def test_conv3x3_forward_and_stats(B, H, W, Cin, Cout):
     ops.pack_weights(w.to(DEV), wf, None)
     y = torch.empty(B, H, W, Cout, device=DEV)
     rows, tiles = ops.conv_stats_rows(B, H, W, Cout)
-    stats = torch.zeros(rows, 2, Cout, device=DEV)
+    stats = torch.zeros(2, Cout, rows, device=DEV)
     ops.conv_fwd(nhwc(x).to(DEV), wf, y, stats, B, H, W, Cin, Cout, ops.TAPS3X3)
     check(nchw(y.cpu()), ref, 5e-6)
-    s = stats.cpu().double()
+    s = stats.cpu().double().permute(2, 0, 1)      # [rows][2][Cout]
     refn = nhwc(ref)
     np.testing.assert_allclose(s[:, 0].sum(0).numpy(), refn.sum((0, 1, 2)).numpy(), rtol=1e-4, atol=1e-3)
     np.testing.assert_allclose(s[:, 1].sum(0).numpy(), (refn ** 2).sum((0, 1, 2)).numpy(), rtol=1e-4, atol=1e-3)
