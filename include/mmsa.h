@@ -152,6 +152,28 @@ MMSA_API int mmsa_ln_scale_bwd(const float* dy, int ldy, const float* x, const f
                                const float* scale, const float* keep, const float* stats, float* dx, float* dgamma,
                                float* dbeta, float* dscale, float* scratch, int B, int N, void* stream);
 /* (w0,w1) = softmax(att[b]); fused = P[:, :Hd]*w0 + P[:, Hd:]*w1   (:275-283) */
+/* ---- fused fusion head of the 'both' model: multimodal_model.py:216-225 (normaliser), :263-285 (fusion),
+ *      :393-404 (classifier).  One workgroup per utterance carries the row through every layer.
+ * ptrs_host: host array of mmsa_head_both_slots() device pointers (float unless noted), in this order:
+ *   inputs and parameters: a_feat[B,A] t_feat[B,T] an_g an_b a_scale[1] tn_g tn_b t_scale[1] keep_a[1]|null
+ *     keep_t[1]|null wpa[Hd,A] bpa gpa bepa wpt[Hd,T] bpt gpt bept watt[2,2Hd] batt w0[N0,Hd] b0 g0 be0
+ *     w1[N1,N0] b1 g1 be1 w2[C,N1] b2
+ *   saved by the forward: an[B,A] tn[B,T] an_stats[2B] tn_stats[2B] pa_pre[B,Hd] pa_stats[2B] pt_pre pt_stats
+ *     P[B,2Hd] att[B,2] wts[B,2] fused[B,Hd] c0_pre[B,N0] c0_stats h1[B,N0] c1_pre[B,N1] c1_stats h2[B,N1]
+ *     logits[B,C]
+ *   backward: dlogits[B,C] (in) c1_dpre c1_dln c0_dpre c0_dln att_dpre[B,2] pa_dpre pa_dln pt_dpre pt_dln
+ *     an_dln[B,A] tn_dln[B,T] a_dspart[B] t_dspart[B] d_afeat[B,A] d_tfeat[B,T]
+ *   parameter gradients (shapes of the parameters): dwpa dbpa dgpa dbepa dwpt dbpt dgpt dbept dwatt dbatt dw0 db0
+ *     dg0 dbe0 dw1 db1 dg1 dbe1 dw2 db2 dan_g dan_b da_scale dtn_g dtn_b dt_scale
+ * Slots a call does not use may be null.  A, T, Hd, N0, N1 <= 512 and multiples of 4; weights 16-byte aligned.
+ * Dropout (p after each projector and the first classifier layer, p/2 after the second) uses seeds seed+1..seed+4. */
+MMSA_API int mmsa_head_both_slots(void);
+MMSA_API int mmsa_head_both_fwd(const void* const* ptrs_host, int nptrs, int B, int A, int T, int Hd, int N0, int N1,
+                                int C, float drop_p, unsigned long long seed, void* stream);
+MMSA_API int mmsa_head_both_bwd(const void* const* ptrs_host, int nptrs, int B, int A, int T, int Hd, int N0, int N1,
+                                int C, float drop_p, unsigned long long seed, void* stream);
+MMSA_API int mmsa_head_both_bwd_params(const void* const* ptrs_host, int nptrs, int B, int A, int T, int Hd, int N0,
+                                       int N1, int C, void* stream);
 MMSA_API int mmsa_fusion_mix_fwd(const float* P, const float* att, float* wts, float* fused, int B, int Hd,
                                  void* stream);
 MMSA_API int mmsa_fusion_mix_bwd(const float* dfused, const float* P, const float* wts, float* dP, float* datt, int B,

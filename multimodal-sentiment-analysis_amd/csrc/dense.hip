@@ -25,15 +25,6 @@ __device__ __forceinline__ float gelu_df(float x) {
   return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
 }
 
-// counter-based uniform in [0,1): one 64-bit mix per element (dropout masks; not comparable with torch's RNG)
-__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
-
 // out[b][n0 .. n0+63] = X[b] W^T + bias.  grid = (B, ceil(N/64)); every wave owns 16 outputs and computes four of
 // them at a time (independent weight-row loads stay in flight); lanes run along K, so weight rows are read coalesced.
 __global__ __launch_bounds__(256) void dense_matvec_kernel(const float* __restrict__ X, int ldx,

@@ -1,0 +1,472 @@
+// The fusion head of the 'both' model as two row-local kernels (forward, data-gradient backward) and one
+// parameter-gradient kernel.
+//
+// Reference semantics: `CNN implementation/multimodal_model.py:216-225` (MultifactorFeatureNormalizer: LayerNorm x
+// learnable scale per modality), `:263-285` (ModalityFusion: modality dropout, Linear+LayerNorm+ReLU+Dropout per
+// modality, Linear(2H,2)+softmax, weighted sum), `:393-404` (fusion classifier: Linear, LN, ReLU, Dropout x2, Linear).
+//
+// Every layer of the head is row-local (LayerNorm, not BatchNorm), so one workgroup of 1024 threads carries one
+// utterance through the whole stack with activations in LDS; the weights (0.8 MB) stream from L2.  The saved
+// activations and the per-layer gradients are also written to HBM in the layout of the layer-by-layer kernels
+// (dense.hip), so the parameter gradients, which sum over utterances, are formed by one further launch off the
+// critical path.  Dropout masks come from the same counter-based generator as the layer-by-layer kernels with the
+// same (seed, element) keys, so both paths draw identical masks.
+#include "mmsa_common.h"
+
+namespace {
+
+constexpr int HT = 1024;     // threads per workgroup
+constexpr int LPR = 16;      // lanes per output row in the forward mat-vec
+constexpr float LN_EPS = 1e-5f;
+
+// slots of the pointer table (device pointers; see include/mmsa.h)
+enum Slot {
+  S_AFEAT, S_TFEAT, S_AN_G, S_AN_B, S_A_SCALE, S_TN_G, S_TN_B, S_T_SCALE, S_KEEP_A, S_KEEP_T,
+  S_WPA, S_BPA, S_GPA, S_BEPA, S_WPT, S_BPT, S_GPT, S_BEPT, S_WATT, S_BATT,
+  S_W0, S_B0, S_G0, S_BE0, S_W1, S_B1, S_G1, S_BE1, S_W2, S_B2,
+  S_AN, S_TN, S_AN_STATS, S_TN_STATS, S_PA_PRE, S_PA_STATS, S_PT_PRE, S_PT_STATS, S_P, S_ATT, S_WTS, S_FUSED,
+  S_C0_PRE, S_C0_STATS, S_H1, S_C1_PRE, S_C1_STATS, S_H2, S_LOGITS,
+  S_DLOGITS, S_C1_DPRE, S_C1_DLN, S_C0_DPRE, S_C0_DLN, S_ATT_DPRE, S_PA_DPRE, S_PA_DLN, S_PT_DPRE, S_PT_DLN,
+  S_AN_DLN, S_TN_DLN, S_A_DSPART, S_T_DSPART, S_D_AFEAT, S_D_TFEAT,
+  S_DWPA, S_DBPA, S_DGPA, S_DBEPA, S_DWPT, S_DBPT, S_DGPT, S_DBEPT, S_DWATT, S_DBATT,
+  S_DW0, S_DB0, S_DG0, S_DBE0, S_DW1, S_DB1, S_DG1, S_DBE1, S_DW2, S_DB2,
+  S_DAN_G, S_DAN_B, S_DA_SCALE, S_DTN_G, S_DTN_B, S_DT_SCALE,
+  S_COUNT
+};
+
+struct HeadPtrs {
+  void* p[S_COUNT];
+};
+struct HeadDims {
+  int B, A, T, Hd, N0, N1, C;
+  float drop_p;
+  unsigned long long seed;
+};
+
+__device__ __forceinline__ const float* cf(const HeadPtrs& h, int s) { return static_cast<const float*>(h.p[s]); }
+__device__ __forceinline__ float* mf(const HeadPtrs& h, int s) { return static_cast<float*>(h.p[s]); }
+
+// out[n] = bias[n] + sum_k W[n][k] x[k] for n < N (x, out in LDS; K a multiple of 4, rows of W 16-byte aligned).
+// Sixteen lanes share an output row and read it in 16-byte pieces (256 contiguous bytes per row and step), 64 rows
+// per pass over the workgroup; two passes are in flight at a time.
+__device__ __forceinline__ void matvec(const float* __restrict__ W, const float* __restrict__ bias, const float* x,
+                                       float* out, int K, int N) {
+  const int t = threadIdx.x, sub = t % LPR, rloc = t / LPR;
+  constexpr int RP = HT / LPR;
+  for (int n0 = 0; n0 < N; n0 += 2 * RP) {
+    const int na = n0 + rloc, nb = n0 + RP + rloc;
+    const float* wa = W + (long)min(na, N - 1) * K;
+    const float* wb = W + (long)min(nb, N - 1) * K;
+    float a = 0.f, b = 0.f;
+    for (int k = 4 * sub; k < K; k += 4 * LPR) {
+      const f32x4 x4 = *reinterpret_cast<const f32x4*>(x + k);
+      const f32x4 u = *reinterpret_cast<const f32x4*>(wa + k);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wb + k);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a = fmaf(u[e], x4[e], a);
+        b = fmaf(v[e], x4[e], b);
+      }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) {
+      a += __shfl_xor(a, o, 64);
+      b += __shfl_xor(b, o, 64);
+    }
+    if (sub == 0) {
+      if (na < N) out[na] = a + (bias ? bias[na] : 0.f);
+      if (nb < N) out[nb] = b + (bias ? bias[nb] : 0.f);
+    }
+  }
+}
+
+// dx[k] (= or +=) sum_n g[n] W[n][k] for k < K (g, dx in LDS).  Threads run along k (coalesced rows of W); the sum over
+// n is split over HT / Kp thread groups and combined through `part` ([HT] floats of LDS) in fixed order.
+__device__ __forceinline__ void matvec_t(const float* __restrict__ W, const float* g, float* dx, float* part, int K,
+                                         int N, bool accumulate) {
+  const int t = threadIdx.x;
+  const int Kp = (K + 63) & ~63;
+  const int G = HT / Kp;
+  const int kl = t % Kp, grp = t / Kp;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (kl < K && grp < G) {
+    int n = grp;
+    for (; n + 3 * G < N; n += 4 * G) {
+      a0 = fmaf(g[n], W[(long)n * K + kl], a0);
+      a1 = fmaf(g[n + G], W[(long)(n + G) * K + kl], a1);
+      a2 = fmaf(g[n + 2 * G], W[(long)(n + 2 * G) * K + kl], a2);
+      a3 = fmaf(g[n + 3 * G], W[(long)(n + 3 * G) * K + kl], a3);
+    }
+    for (; n < N; n += G) a0 = fmaf(g[n], W[(long)n * K + kl], a0);
+  }
+  __syncthreads();   // the previous user of `part` is done
+  part[t] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (t < K) {
+    float s = 0.f;
+    for (int i = 0; i < G; ++i) s += part[i * Kp + t];
+    dx[t] = accumulate ? dx[t] + s : s;
+  }
+  __syncthreads();
+}
+
+// mean and 1/sqrt(var + eps) of v[0..N) (LDS), two passes as torch's LayerNorm
+__device__ __forceinline__ void row_stats(const float* v, int N, float* red, float& mean, float& rstd) {
+  float s = 0.f;
+  for (int n = threadIdx.x; n < N; n += HT) s += v[n];
+  mean = block_sum(s, red) / (float)N;
+  float q = 0.f;
+  for (int n = threadIdx.x; n < N; n += HT) {
+    const float d = v[n] - mean;
+    q = fmaf(d, d, q);
+  }
+  rstd = 1.0f / sqrtf(block_sum(q, red) / (float)N + LN_EPS);
+}
+
+// y = dropout(relu(LN(pre) * gamma + beta)); pre (LDS) is also stored to HBM with its statistics
+__device__ __forceinline__ void ln_relu_drop(const float* pre, int N, const float* __restrict__ gamma,
+                                             const float* __restrict__ beta, float* y_lds, float* y_g, float* pre_g,
+                                             float* stats_g, int b, float drop_p, unsigned long long seed, float* red) {
+  float mean, rstd;
+  row_stats(pre, N, red, mean, rstd);
+  if (threadIdx.x == 0) {
+    stats_g[2 * b] = mean;
+    stats_g[2 * b + 1] = rstd;
+  }
+  const float ks = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+  for (int n = threadIdx.x; n < N; n += HT) {
+    const float p = pre[n];
+    pre_g[(long)b * N + n] = p;
+    float v = fmaxf(fmaf((p - mean) * rstd, gamma[n], beta[n]), 0.f);
+    if (drop_p > 0.f) v = hash_uniform(seed, (unsigned long long)b * N + n) >= drop_p ? v * ks : 0.f;
+    y_lds[n] = v;
+    y_g[n] = v;
+  }
+  __syncthreads();
+}
+
+// gradient through dropout, ReLU and LayerNorm of one Linear+LN+ReLU layer: d (LDS, gradient w.r.t. the layer output)
+// -> g (LDS, gradient w.r.t. the linear output); dLn and dPre rows go to HBM for the parameter-gradient kernel
+__device__ __forceinline__ void ln_relu_drop_bwd(const float* d_in, float* g, int N, const float* __restrict__ pre_g,
+                                                 const float* __restrict__ stats_g, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float* dln_g, float* dpre_g, int b,
+                                                 float drop_p, unsigned long long seed, float* red) {
+  const float mean = stats_g[2 * b], rstd = stats_g[2 * b + 1];
+  const float ks = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+  float s1 = 0.f, s2 = 0.f;
+  for (int n = threadIdx.x; n < N; n += HT) {
+    float d = d_in[n];
+    if (drop_p > 0.f) d = hash_uniform(seed, (unsigned long long)b * N + n) >= drop_p ? d * ks : 0.f;
+    const float xh = (pre_g[(long)b * N + n] - mean) * rstd;
+    const float y = fmaf(xh, gamma[n], beta[n]);
+    d = y > 0.f ? d : 0.f;
+    dln_g[(long)b * N + n] = d;
+    const float dg = d * gamma[n];
+    g[n] = dg;
+    s1 += dg;
+    s2 = fmaf(dg, xh, s2);
+  }
+  s1 = block_sum(s1, red) / (float)N;
+  s2 = block_sum(s2, red) / (float)N;
+  for (int n = threadIdx.x; n < N; n += HT) {
+    const float xh = (pre_g[(long)b * N + n] - mean) * rstd;
+    const float v = rstd * (g[n] - s1 - xh * s2);
+    g[n] = v;
+    dpre_g[(long)b * N + n] = v;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(HT) void head_both_fwd_kernel(const HeadPtrs h, const HeadDims d) {
+  __shared__ __attribute__((aligned(16))) float s_in[1024];    // normalised audio | text features
+  __shared__ __attribute__((aligned(16))) float s_pre[1024];   // linear outputs of the current layer
+  __shared__ __attribute__((aligned(16))) float s_P[1024];     // projected audio | text
+  __shared__ __attribute__((aligned(16))) float s_x[512];      // fused / hidden vectors
+  __shared__ float red[32];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int A = d.A, T = d.T, Hd = d.Hd;
+
+  // feature normaliser: LayerNorm * scale * modality keep flag
+  for (int n = t; n < A; n += HT) s_pre[n] = cf(h, S_AFEAT)[(long)b * A + n];
+  for (int n = t; n < T; n += HT) s_pre[512 + n] = cf(h, S_TFEAT)[(long)b * T + n];
+  __syncthreads();
+  {
+    float mean, rstd;
+    row_stats(s_pre, A, red, mean, rstd);
+    if (t == 0) { mf(h, S_AN_STATS)[2 * b] = mean; mf(h, S_AN_STATS)[2 * b + 1] = rstd; }
+    const float sc = cf(h, S_A_SCALE)[0] * (h.p[S_KEEP_A] ? cf(h, S_KEEP_A)[0] : 1.f);
+    for (int n = t; n < A; n += HT) {
+      const float v = fmaf((s_pre[n] - mean) * rstd, cf(h, S_AN_G)[n], cf(h, S_AN_B)[n]) * sc;
+      s_in[n] = v;
+      mf(h, S_AN)[(long)b * A + n] = v;
+    }
+    row_stats(s_pre + 512, T, red, mean, rstd);
+    if (t == 0) { mf(h, S_TN_STATS)[2 * b] = mean; mf(h, S_TN_STATS)[2 * b + 1] = rstd; }
+    const float st = cf(h, S_T_SCALE)[0] * (h.p[S_KEEP_T] ? cf(h, S_KEEP_T)[0] : 1.f);
+    for (int n = t; n < T; n += HT) {
+      const float v = fmaf((s_pre[512 + n] - mean) * rstd, cf(h, S_TN_G)[n], cf(h, S_TN_B)[n]) * st;
+      s_in[512 + n] = v;
+      mf(h, S_TN)[(long)b * T + n] = v;
+    }
+  }
+  __syncthreads();
+
+  // the two projectors: Linear -> LayerNorm -> ReLU -> Dropout
+  matvec(cf(h, S_WPA), cf(h, S_BPA), s_in, s_pre, A, Hd);
+  matvec(cf(h, S_WPT), cf(h, S_BPT), s_in + 512, s_pre + 512, T, Hd);
+  __syncthreads();
+  float* Pg = mf(h, S_P) + (long)b * 2 * Hd;
+  ln_relu_drop(s_pre, Hd, cf(h, S_GPA), cf(h, S_BEPA), s_P, Pg, mf(h, S_PA_PRE), mf(h, S_PA_STATS), b, d.drop_p,
+               d.seed + 1, red);
+  ln_relu_drop(s_pre + 512, Hd, cf(h, S_GPT), cf(h, S_BEPT), s_P + Hd, Pg + Hd, mf(h, S_PT_PRE), mf(h, S_PT_STATS), b,
+               d.drop_p, d.seed + 2, red);
+
+  // attention over the two modalities and the weighted sum
+  matvec(cf(h, S_WATT), cf(h, S_BATT), s_P, s_pre, 2 * Hd, 2);
+  __syncthreads();
+  {
+    const float a0 = s_pre[0], a1 = s_pre[1];
+    const float m = fmaxf(a0, a1);
+    const float e0 = expf(a0 - m), e1 = expf(a1 - m);
+    const float w0 = e0 / (e0 + e1), w1 = e1 / (e0 + e1);
+    if (t == 0) {
+      mf(h, S_ATT)[2 * b] = a0; mf(h, S_ATT)[2 * b + 1] = a1;
+      mf(h, S_WTS)[2 * b] = w0; mf(h, S_WTS)[2 * b + 1] = w1;
+    }
+    for (int n = t; n < Hd; n += HT) {
+      const float v = s_P[n] * w0 + s_P[Hd + n] * w1;
+      s_x[n] = v;
+      mf(h, S_FUSED)[(long)b * Hd + n] = v;
+    }
+  }
+  __syncthreads();
+
+  // classifier
+  matvec(cf(h, S_W0), cf(h, S_B0), s_x, s_pre, Hd, d.N0);
+  __syncthreads();
+  ln_relu_drop(s_pre, d.N0, cf(h, S_G0), cf(h, S_BE0), s_x, mf(h, S_H1) + (long)b * d.N0, mf(h, S_C0_PRE),
+               mf(h, S_C0_STATS), b, d.drop_p, d.seed + 3, red);
+  matvec(cf(h, S_W1), cf(h, S_B1), s_x, s_pre, d.N0, d.N1);
+  __syncthreads();
+  ln_relu_drop(s_pre, d.N1, cf(h, S_G1), cf(h, S_BE1), s_x, mf(h, S_H2) + (long)b * d.N1, mf(h, S_C1_PRE),
+               mf(h, S_C1_STATS), b, 0.5f * d.drop_p, d.seed + 4, red);
+  matvec(cf(h, S_W2), cf(h, S_B2), s_x, s_pre, d.N1, d.C);
+  __syncthreads();
+  for (int n = t; n < d.C; n += HT) mf(h, S_LOGITS)[(long)b * d.C + n] = s_pre[n];
+}
+
+__global__ __launch_bounds__(HT) void head_both_bwd_kernel(const HeadPtrs h, const HeadDims d) {
+  __shared__ float s_d[1024];     // gradient w.r.t. the current layer's output
+  __shared__ float s_g[1024];     // gradient w.r.t. the current layer's linear output
+  __shared__ float s_dP[1024];    // gradient w.r.t. the projected audio | text
+  __shared__ float part[HT];
+  __shared__ float red[32];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int A = d.A, T = d.T, Hd = d.Hd, N0 = d.N0, N1 = d.N1, C = d.C;
+
+  // logits layer (plain Linear): its dPre is the incoming gradient itself
+  for (int n = t; n < C; n += HT) s_g[n] = cf(h, S_DLOGITS)[(long)b * C + n];
+  __syncthreads();
+  matvec_t(cf(h, S_W2), s_g, s_d, part, N1, C, false);
+  ln_relu_drop_bwd(s_d, s_g, N1, cf(h, S_C1_PRE), cf(h, S_C1_STATS), cf(h, S_G1), cf(h, S_BE1), mf(h, S_C1_DLN),
+                   mf(h, S_C1_DPRE), b, 0.5f * d.drop_p, d.seed + 4, red);
+  matvec_t(cf(h, S_W1), s_g, s_d, part, N0, N1, false);
+  ln_relu_drop_bwd(s_d, s_g, N0, cf(h, S_C0_PRE), cf(h, S_C0_STATS), cf(h, S_G0), cf(h, S_BE0), mf(h, S_C0_DLN),
+                   mf(h, S_C0_DPRE), b, d.drop_p, d.seed + 3, red);
+  matvec_t(cf(h, S_W0), s_g, s_d, part, Hd, N0, false);      // s_d = d fused
+
+  // weighted sum and the softmax over the two attention scores
+  {
+    const float* Pg = cf(h, S_P) + (long)b * 2 * Hd;
+    const float w0 = cf(h, S_WTS)[2 * b], w1 = cf(h, S_WTS)[2 * b + 1];
+    float d0 = 0.f, d1 = 0.f;
+    for (int n = t; n < Hd; n += HT) {
+      const float df = s_d[n];
+      d0 = fmaf(df, Pg[n], d0);
+      d1 = fmaf(df, Pg[Hd + n], d1);
+      s_dP[n] = df * w0;
+      s_dP[Hd + n] = df * w1;
+    }
+    d0 = block_sum(d0, red);
+    d1 = block_sum(d1, red);
+    const float dot = w0 * d0 + w1 * d1;
+    const float g0 = w0 * (d0 - dot), g1 = w1 * (d1 - dot);
+    if (t == 0) {
+      s_g[0] = g0; s_g[1] = g1;
+      mf(h, S_ATT_DPRE)[2 * b] = g0; mf(h, S_ATT_DPRE)[2 * b + 1] = g1;
+    }
+    __syncthreads();
+  }
+  matvec_t(cf(h, S_WATT), s_g, s_dP, part, 2 * Hd, 2, true);
+
+  // projectors, then the feature normaliser
+  ln_relu_drop_bwd(s_dP, s_g, Hd, cf(h, S_PA_PRE), cf(h, S_PA_STATS), cf(h, S_GPA), cf(h, S_BEPA), mf(h, S_PA_DLN),
+                   mf(h, S_PA_DPRE), b, d.drop_p, d.seed + 1, red);
+  matvec_t(cf(h, S_WPA), s_g, s_d, part, A, Hd, false);       // s_d[0..A) = d an
+  ln_relu_drop_bwd(s_dP + Hd, s_g, Hd, cf(h, S_PT_PRE), cf(h, S_PT_STATS), cf(h, S_GPT), cf(h, S_BEPT),
+                   mf(h, S_PT_DLN), mf(h, S_PT_DPRE), b, d.drop_p, d.seed + 2, red);
+  matvec_t(cf(h, S_WPT), s_g, s_d + 512, part, T, Hd, false);  // s_d[512..512+T) = d tn
+
+#pragma unroll 1
+  for (int which = 0; which < 2; ++which) {
+    const int N = which ? T : A;
+    const float* dy = s_d + (which ? 512 : 0);
+    const float* x = cf(h, which ? S_TFEAT : S_AFEAT) + (long)b * N;
+    const float* gam = cf(h, which ? S_TN_G : S_AN_G);
+    const float* bet = cf(h, which ? S_TN_B : S_AN_B);
+    const float* stats = cf(h, which ? S_TN_STATS : S_AN_STATS);
+    const float* keep = cf(h, which ? S_KEEP_T : S_KEEP_A);
+    float* dln = mf(h, which ? S_TN_DLN : S_AN_DLN) + (long)b * N;
+    float* dx = mf(h, which ? S_D_TFEAT : S_D_AFEAT) + (long)b * N;
+    const float mean = stats[2 * b], rstd = stats[2 * b + 1];
+    const float kp = keep ? keep[0] : 1.f;
+    const float sc = cf(h, which ? S_T_SCALE : S_A_SCALE)[0] * kp;
+    float s1 = 0.f, s2 = 0.f, ds = 0.f;
+    for (int n = t; n < N; n += HT) {
+      const float dv = dy[n];
+      const float xh = (x[n] - mean) * rstd;
+      const float dl = dv * sc;
+      dln[n] = dl;
+      s_g[n] = dl;
+      ds = fmaf(dv * kp, fmaf(xh, gam[n], bet[n]), ds);
+      const float dg = dl * gam[n];
+      s1 += dg;
+      s2 = fmaf(dg, xh, s2);
+    }
+    s1 = block_sum(s1, red) / (float)N;
+    s2 = block_sum(s2, red) / (float)N;
+    ds = block_sum(ds, red);
+    if (t == 0) mf(h, which ? S_T_DSPART : S_A_DSPART)[b] = ds;
+    for (int n = t; n < N; n += HT) {
+      const float xh = (x[n] - mean) * rstd;
+      dx[n] = rstd * (s_g[n] * gam[n] - s1 - xh * s2);
+    }
+    __syncthreads();
+  }
+}
+
+// Parameter gradients of the whole head in one launch (sums over the B utterances, fixed order).
+// blockIdx.y selects the layer: 0..5 dense layers (pa, pt, att, c0, c1, c2), 6 / 7 the audio / text normaliser.
+struct WLayer {
+  int dpre, dln, pre, stats, x, ldx, dw, db, dg, dbe, K, N;
+};
+
+__global__ __launch_bounds__(256) void head_both_wgrad_kernel(const HeadPtrs h, const HeadDims d) {
+  const int B = d.B, A = d.A, T = d.T, Hd = d.Hd, N0 = d.N0, N1 = d.N1, C = d.C;
+  const int L = blockIdx.y;
+  if (L >= 6) {
+    const bool txt = L == 7;
+    const int N = txt ? T : A;
+    const float* dLn = cf(h, txt ? S_TN_DLN : S_AN_DLN);
+    const float* x = cf(h, txt ? S_TFEAT : S_AFEAT);
+    const float* stats = cf(h, txt ? S_TN_STATS : S_AN_STATS);
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) {
+      float sg = 0.f, sb = 0.f;
+      for (int b = 0; b < B; ++b) {
+        const float dv = dLn[(long)b * N + n];
+        sg = fmaf(dv, (x[(long)b * N + n] - stats[2 * b]) * stats[2 * b + 1], sg);
+        sb += dv;
+      }
+      mf(h, txt ? S_DTN_G : S_DAN_G)[n] = sg;
+      mf(h, txt ? S_DTN_B : S_DAN_B)[n] = sb;
+    }
+    if (n == 0) {
+      const float* part = cf(h, txt ? S_T_DSPART : S_A_DSPART);
+      float s = 0.f;
+      for (int b = 0; b < B; ++b) s += part[b];
+      mf(h, txt ? S_DT_SCALE : S_DA_SCALE)[0] = s;
+    }
+    return;
+  }
+  WLayer w;
+  switch (L) {
+    case 0: w = {S_PA_DPRE, S_PA_DLN, S_PA_PRE, S_PA_STATS, S_AN, A, S_DWPA, S_DBPA, S_DGPA, S_DBEPA, A, Hd}; break;
+    case 1: w = {S_PT_DPRE, S_PT_DLN, S_PT_PRE, S_PT_STATS, S_TN, T, S_DWPT, S_DBPT, S_DGPT, S_DBEPT, T, Hd}; break;
+    case 2: w = {S_ATT_DPRE, -1, -1, -1, S_P, 2 * Hd, S_DWATT, S_DBATT, -1, -1, 2 * Hd, 2}; break;
+    case 3: w = {S_C0_DPRE, S_C0_DLN, S_C0_PRE, S_C0_STATS, S_FUSED, Hd, S_DW0, S_DB0, S_DG0, S_DBE0, Hd, N0}; break;
+    case 4: w = {S_C1_DPRE, S_C1_DLN, S_C1_PRE, S_C1_STATS, S_H1, N0, S_DW1, S_DB1, S_DG1, S_DBE1, N0, N1}; break;
+    default: w = {S_DLOGITS, -1, -1, -1, S_H2, N1, S_DW2, S_DB2, -1, -1, N1, C}; break;
+  }
+  const float* dPre = cf(h, w.dpre);
+  const float* X = cf(h, w.x);
+  const long nk = (long)w.N * w.K;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nk + w.N; i += (long)gridDim.x * blockDim.x) {
+    if (i < nk) {
+      const int n = (int)(i / w.K), k = (int)(i - (long)n * w.K);
+      float a = 0.f;
+#pragma unroll 8
+      for (int b = 0; b < B; ++b) a = fmaf(dPre[(long)b * w.N + n], X[(long)b * w.ldx + k], a);
+      mf(h, w.dw)[i] = a;
+    } else {
+      const int n = (int)(i - nk);
+      float sb = 0.f, sg = 0.f, sbt = 0.f;
+      for (int b = 0; b < B; ++b) {
+        sb += dPre[(long)b * w.N + n];
+        if (w.dg >= 0) {
+          const float xh = (cf(h, w.pre)[(long)b * w.N + n] - cf(h, w.stats)[2 * b]) * cf(h, w.stats)[2 * b + 1];
+          const float dv = cf(h, w.dln)[(long)b * w.N + n];
+          sg = fmaf(dv, xh, sg);
+          sbt += dv;
+        }
+      }
+      mf(h, w.db)[n] = sb;
+      if (w.dg >= 0) { mf(h, w.dg)[n] = sg; mf(h, w.dbe)[n] = sbt; }
+    }
+  }
+}
+
+int fill(HeadPtrs& hp, HeadDims& hd, const void* const* ptrs, int nptrs, int first_required, int last_required, int B,
+         int A, int T, int Hd, int N0, int N1, int C, float drop_p, unsigned long long seed) {
+  if (!ptrs || nptrs != S_COUNT) return MMSA_ERR_ARG;
+  if (B <= 0 || B > 65535 || A <= 0 || T <= 0 || Hd <= 0 || N0 <= 0 || N1 <= 0 || C <= 0) return MMSA_ERR_ARG;
+  if (A > 512 || T > 512 || Hd > 512 || N0 > 512 || N1 > 512 || C > 512) return MMSA_ERR_LIMIT;
+  if ((A | T | Hd | N0 | N1) & 3) return MMSA_ERR_ARG;        // 16-byte pieces of the weight rows
+  if (!(drop_p >= 0.f && drop_p < 1.f)) return MMSA_ERR_ARG;
+  for (int i = 0; i < S_COUNT; ++i) hp.p[i] = const_cast<void*>(ptrs[i]);
+  for (int i = first_required; i <= last_required; ++i)
+    if (!hp.p[i] && i != S_KEEP_A && i != S_KEEP_T) return MMSA_ERR_ARG;
+  static const int weights[] = {S_WPA, S_WPT, S_WATT, S_W0, S_W1, S_W2};
+  for (int s : weights)
+    if (reinterpret_cast<uintptr_t>(hp.p[s]) & 15) return MMSA_ERR_ARG;
+  hd = HeadDims{B, A, T, Hd, N0, N1, C, drop_p, seed};
+  return MMSA_OK;
+}
+
+}  // namespace
+
+MMSA_EXPORT int mmsa_head_both_slots() { return S_COUNT; }
+
+// Forward of the fusion head: slots a_feat .. b2 are read, slots an .. logits are written.
+MMSA_EXPORT int mmsa_head_both_fwd(const void* const* ptrs_host, int nptrs, int B, int A, int T, int Hd, int N0, int N1,
+                                   int C, float drop_p, unsigned long long seed, void* stream) {
+  HeadPtrs hp;
+  HeadDims hd;
+  const int rc = fill(hp, hd, ptrs_host, nptrs, S_AFEAT, S_LOGITS, B, A, T, Hd, N0, N1, C, drop_p, seed);
+  if (rc != MMSA_OK) return rc;
+  hipLaunchKernelGGL(head_both_fwd_kernel, dim3(B), dim3(HT), 0, mmsa_stream(stream), hp, hd);
+  return mmsa_launch_status();
+}
+
+// Data-gradient backward: reads dlogits and what the forward saved; writes the per-layer dPre / dLn rows, the two
+// per-utterance scale-gradient partials and d_afeat / d_tfeat.
+MMSA_EXPORT int mmsa_head_both_bwd(const void* const* ptrs_host, int nptrs, int B, int A, int T, int Hd, int N0, int N1,
+                                   int C, float drop_p, unsigned long long seed, void* stream) {
+  HeadPtrs hp;
+  HeadDims hd;
+  const int rc = fill(hp, hd, ptrs_host, nptrs, S_AFEAT, S_D_TFEAT, B, A, T, Hd, N0, N1, C, drop_p, seed);
+  if (rc != MMSA_OK) return rc;
+  hipLaunchKernelGGL(head_both_bwd_kernel, dim3(B), dim3(HT), 0, mmsa_stream(stream), hp, hd);
+  return mmsa_launch_status();
+}
+
+// Parameter gradients (all slots must be set): must follow mmsa_head_both_bwd in stream order.
+MMSA_EXPORT int mmsa_head_both_bwd_params(const void* const* ptrs_host, int nptrs, int B, int A, int T, int Hd, int N0,
+                                          int N1, int C, void* stream) {
+  HeadPtrs hp;
+  HeadDims hd;
+  const int rc = fill(hp, hd, ptrs_host, nptrs, S_AFEAT, S_COUNT - 1, B, A, T, Hd, N0, N1, C, 0.f, 0);
+  if (rc != MMSA_OK) return rc;
+  hipLaunchKernelGGL(head_both_wgrad_kernel, dim3(96, 8), dim3(256), 0, mmsa_stream(stream), hp, hd);
+  return mmsa_launch_status();
+}

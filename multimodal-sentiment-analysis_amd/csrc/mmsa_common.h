@@ -29,6 +29,15 @@ static inline int mmsa_cdiv(long a, long b) { return static_cast<int>((a + b - 1
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// counter-based uniform in [0,1): one 64-bit mix per element (dropout masks; not comparable with torch's RNG)
+__device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
 // ---- wave / block reductions -------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -68,8 +68,97 @@ def _finish(st, ws, logits, labels, B, need_grad):
     return st
 
 
+def _use_layers() -> bool:
+    """MMSA_HEAD=layers selects the layer-by-layer launch sequence (kept for cross-checking the fused kernels)."""
+    import os
+    return os.environ.get("MMSA_HEAD", "") == "layers"
+
+
 def head_forward_both(model, a_feat, t_feat, labels, training, keep_a, keep_t, drop_p, seed, need_grad,
                       ws: Workspace, logits_out=None):
+    """Fused path: the whole head is one launch (one workgroup per utterance) followed by softmax / CE."""
+    if _use_layers():
+        return head_forward_both_layers(model, a_feat, t_feat, labels, training, keep_a, keep_t, drop_p, seed,
+                                        need_grad, ws, logits_out)
+    B, A = a_feat.shape
+    T = t_feat.shape[1]
+    fn, fu, cl = model.feature_normalizer, model.fusion_layer, model.classifier
+    Hd = fu.audio_projector[0].weight.shape[0]
+    N0, N1, C = cl[0].weight.shape[0], cl[4].weight.shape[0], cl[8].weight.shape[0]
+    p = drop_p if training else 0.0
+    st = SimpleNamespace(kind="both", one_launch=True, B=B, dims=(B, A, T, Hd, N0, N1, C), p=p, seed=seed)
+    logits = logits_out if logits_out is not None else ws.buf("head.logits", (B, C))
+    t = {
+        "a_feat": a_feat.contiguous(), "t_feat": t_feat.contiguous(),
+        "an_g": fn.audio_norm.weight, "an_b": fn.audio_norm.bias, "a_scale": fn.audio_scale,
+        "tn_g": fn.text_norm.weight, "tn_b": fn.text_norm.bias, "t_scale": fn.text_scale,
+        "keep_a": keep_a, "keep_t": keep_t,
+        "wpa": fu.audio_projector[0].weight, "bpa": fu.audio_projector[0].bias,
+        "gpa": fu.audio_projector[1].weight, "bepa": fu.audio_projector[1].bias,
+        "wpt": fu.text_projector[0].weight, "bpt": fu.text_projector[0].bias,
+        "gpt": fu.text_projector[1].weight, "bept": fu.text_projector[1].bias,
+        "watt": fu.attention[0].weight, "batt": fu.attention[0].bias,
+        "w0": cl[0].weight, "b0": cl[0].bias, "g0": cl[1].weight, "be0": cl[1].bias,
+        "w1": cl[4].weight, "b1": cl[4].bias, "g1": cl[5].weight, "be1": cl[5].bias,
+        "w2": cl[8].weight, "b2": cl[8].bias,
+        "an": ws.buf("head.an", (B, A)), "tn": ws.buf("head.tn", (B, T)),
+        "an_stats": ws.buf("head.an_stats", 2 * B), "tn_stats": ws.buf("head.tn_stats", 2 * B),
+        "pa_pre": ws.buf("head.pa.pre", (B, Hd)), "pa_stats": ws.buf("head.pa.stats", 2 * B),
+        "pt_pre": ws.buf("head.pt.pre", (B, Hd)), "pt_stats": ws.buf("head.pt.stats", 2 * B),
+        "P": ws.buf("head.P", (B, 2 * Hd)), "att": ws.buf("head.att_out", (B, 2)), "wts": ws.buf("head.wts", 2 * B),
+        "fused": ws.buf("head.fused", (B, Hd)),
+        "c0_pre": ws.buf("head.c0.pre", (B, N0)), "c0_stats": ws.buf("head.c0.stats", 2 * B),
+        "h1": ws.buf("head.h1", (B, N0)),
+        "c1_pre": ws.buf("head.c1.pre", (B, N1)), "c1_stats": ws.buf("head.c1.stats", 2 * B),
+        "h2": ws.buf("head.h2", (B, N1)), "logits": logits,
+    }
+    st.tensors = t
+    ops.head_both("fwd", ops.head_both_table(t), st.dims, p, seed)
+    return _finish(st, ws, logits, labels, B, need_grad)
+
+
+def head_backward_both(model, st, dlogits, grads: Grads, ws: Workspace):
+    """Returns (d_audio_features, d_text_features)."""
+    if not getattr(st, "one_launch", False):
+        return head_backward_both_layers(model, st, dlogits, grads, ws)
+    from .audio import fork
+    B, A, T, Hd, N0, N1, C = st.dims
+    fn, fu, cl = model.feature_normalizer, model.fusion_layer, model.classifier
+    t = st.tensors
+    t.update({
+        "dlogits": dlogits.contiguous(),
+        "c1_dpre": ws.buf("head.c1.dpre", (B, N1)), "c1_dln": ws.buf("head.c1.dln", (B, N1)),
+        "c0_dpre": ws.buf("head.c0.dpre", (B, N0)), "c0_dln": ws.buf("head.c0.dln", (B, N0)),
+        "att_dpre": ws.buf("head.att.dpre", (B, 2)),
+        "pa_dpre": ws.buf("head.pa.dpre", (B, Hd)), "pa_dln": ws.buf("head.pa.dln", (B, Hd)),
+        "pt_dpre": ws.buf("head.pt.dpre", (B, Hd)), "pt_dln": ws.buf("head.pt.dln", (B, Hd)),
+        "an_dln": ws.buf("head.an_dln", (B, A)), "tn_dln": ws.buf("head.tn_dln", (B, T)),
+        "a_dspart": ws.buf("head.a_dspart", B), "t_dspart": ws.buf("head.t_dspart", B),
+        "d_afeat": ws.buf("head.d_afeat", (B, A)), "d_tfeat": ws.buf("head.d_tfeat", (B, T)),
+    })
+    g = grads.of
+    t.update({
+        "dwpa": g(fu.audio_projector[0].weight), "dbpa": g(fu.audio_projector[0].bias),
+        "dgpa": g(fu.audio_projector[1].weight), "dbepa": g(fu.audio_projector[1].bias),
+        "dwpt": g(fu.text_projector[0].weight), "dbpt": g(fu.text_projector[0].bias),
+        "dgpt": g(fu.text_projector[1].weight), "dbept": g(fu.text_projector[1].bias),
+        "dwatt": g(fu.attention[0].weight), "dbatt": g(fu.attention[0].bias),
+        "dw0": g(cl[0].weight), "db0": g(cl[0].bias), "dg0": g(cl[1].weight), "dbe0": g(cl[1].bias),
+        "dw1": g(cl[4].weight), "db1": g(cl[4].bias), "dg1": g(cl[5].weight), "dbe1": g(cl[5].bias),
+        "dw2": g(cl[8].weight), "db2": g(cl[8].bias),
+        "dan_g": g(fn.audio_norm.weight), "dan_b": g(fn.audio_norm.bias), "da_scale": g(fn.audio_scale),
+        "dtn_g": g(fn.text_norm.weight), "dtn_b": g(fn.text_norm.bias), "dt_scale": g(fn.text_scale),
+    })
+    table = ops.head_both_table(t)
+    ops.head_both("bwd", table, st.dims, st.p, st.seed)
+    # the parameter gradients only feed the optimiser: helper stream 2 (joined at the end of the step)
+    with fork(ws, dlogits.device, 2):
+        ops.head_both("bwd_params", table, st.dims)
+    return t["d_afeat"], t["d_tfeat"]
+
+
+def head_forward_both_layers(model, a_feat, t_feat, labels, training, keep_a, keep_t, drop_p, seed, need_grad,
+                             ws: Workspace, logits_out=None):
     B = a_feat.shape[0]
     fn, fu, cl = model.feature_normalizer, model.fusion_layer, model.classifier
     st = SimpleNamespace(kind="both", B=B, a_feat=a_feat, t_feat=t_feat, keep_a=keep_a, keep_t=keep_t)
@@ -101,7 +190,7 @@ def head_forward_both(model, a_feat, t_feat, labels, training, keep_a, keep_t, d
     return _finish(st, ws, logits, labels, B, need_grad)
 
 
-def head_backward_both(model, st, dlogits, grads: Grads, ws: Workspace):
+def head_backward_both_layers(model, st, dlogits, grads: Grads, ws: Workspace):
     """Returns (d_audio_features, d_text_features)."""
     B, Hd = st.B, st.Hd
     fn = model.feature_normalizer

@@ -409,6 +409,37 @@ def ln_scale_bwd(dy, x, gamma, beta, scale, keep, stats, dx, dgamma, dbeta, dsca
               _chk(dx), _chk(dgamma), _chk(dbeta), _chk(dscale), _chk(scratch), B, N, _stream())
 
 
+HEAD_SLOTS = (
+    "a_feat t_feat an_g an_b a_scale tn_g tn_b t_scale keep_a keep_t "
+    "wpa bpa gpa bepa wpt bpt gpt bept watt batt w0 b0 g0 be0 w1 b1 g1 be1 w2 b2 "
+    "an tn an_stats tn_stats pa_pre pa_stats pt_pre pt_stats P att wts fused "
+    "c0_pre c0_stats h1 c1_pre c1_stats h2 logits "
+    "dlogits c1_dpre c1_dln c0_dpre c0_dln att_dpre pa_dpre pa_dln pt_dpre pt_dln "
+    "an_dln tn_dln a_dspart t_dspart d_afeat d_tfeat "
+    "dwpa dbpa dgpa dbepa dwpt dbpt dgpt dbept dwatt dbatt dw0 db0 dg0 dbe0 dw1 db1 dg1 dbe1 dw2 db2 "
+    "dan_g dan_b da_scale dtn_g dtn_b dt_scale").split()
+
+
+def head_both_table(named: dict):
+    """ctypes pointer table for the fused head entry points from {slot name: tensor or None}."""
+    n = _lib.query("mmsa_head_both_slots")
+    if n != len(HEAD_SLOTS):
+        raise _lib.MmsaError("fused head: slot table of the library and of the binding differ")
+    unknown = set(named) - set(HEAD_SLOTS)
+    if unknown:
+        raise KeyError(f"fused head: unknown slots {sorted(unknown)}")
+    return _parr([0 if named.get(k) is None else _chk(named[k], name=k) for k in HEAD_SLOTS])
+
+
+def head_both(which: str, table, dims, drop_p=0.0, seed=0):
+    """which: 'fwd' | 'bwd' | 'bwd_params'; dims = (B, A, T, Hd, N0, N1, C)."""
+    if which == "bwd_params":
+        _lib.call("mmsa_head_both_bwd_params", table, len(HEAD_SLOTS), *[int(d) for d in dims], _stream())
+    else:
+        _lib.call("mmsa_head_both_" + which, table, len(HEAD_SLOTS), *[int(d) for d in dims], float(drop_p),
+                  int(seed), _stream())
+
+
 def fusion_mix_fwd(P, att, wts, fused):
     B, H2 = P.shape
     if att.shape != (B, 2) or wts.numel() != 2 * B or fused.shape != (B, H2 // 2):

@@ -159,3 +159,28 @@ def test_checkpoint_roundtrip_strict():
         c = m2(**model_inputs("both", b))["logits"]
     assert torch.equal(a, c)
     assert m2.state_dict()["audio_model.conv1.1.num_batches_tracked"].dtype == torch.int64
+
+
+@pytest.mark.parametrize("drop", [0.0, 0.4])
+def test_fused_head_equals_layer_by_layer_head(monkeypatch, drop):
+    """The one-launch fusion head and the layer-by-layer launch sequence compute the same function and draw the
+    same dropout masks (same seeds and element keys); only the summation order inside a dot product differs."""
+    b = batch_tensors(1, 8, vocab=SMALL_VOCAB, device=DEV)
+    res = []
+    for mode in ("", "layers"):
+        monkeypatch.setenv("MMSA_HEAD", mode)
+        m = seeded_model("both", vocab=SMALL_VOCAB, fusion_dropout=drop).to(DEV).train()
+        monkeypatch.setattr(m.fusion_layer, "draw_modality_dropout", lambda: (False, False))
+        m.__dict__["_seed_counter"] = 0
+        out = m(**model_inputs("both", b), labels=b["label"])
+        out["loss"].backward()
+        res.append((out["logits"].detach().clone(), float(out["loss"].detach()),
+                    {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+    (l0, loss0, g0), (l1, loss1, g1) = res
+    close(l0, l1.cpu(), 2e-5)
+    assert abs(loss0 - loss1) < 1e-5
+    for k in g0:
+        if is_noise_grad("both", k):
+            continue
+        scale = float(g1[k].abs().max()) + 1e-8
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-4 * scale + 1e-7, k
