@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void stem_apply_pool_kernel(const float* __res
 }
 
 // backward pass 1: route the pooled gradient to the window argmax (first maximum, as torch's max_pool2d),
-// gate by ReLU, accumulate sum(dz) and sum(dz * xhat) per channel.  partial[B*H2][2][32].
+// gate by ReLU, accumulate sum(dz) and sum(dz * xhat) per channel.  partial[2][32][B*H2].
 __global__ __launch_bounds__(256) void stem_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
                                                              const float* __restrict__ bias,
                                                              const float* __restrict__ coeff,
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void stem_bwd_stats_kernel(const float* __rest
     float t = 0.f;
 #pragma unroll
     for (int p = 0; p < 8; ++p) t += red[(p * 2 + which) * 32 + c];
-    partial[((long)blockIdx.x * 2 + which) * STEM_C + c] = t;
+    partial[((long)which * STEM_C + c) * gridDim.x + blockIdx.x] = t;
   }
 }
 
@@ -637,7 +637,7 @@ __global__ void rb_bwd_apply_kernel(const float* __restrict__ dz, const float* _
   }
 }
 
-// ReLU + BN backward statistics for bn1: g = dh * [bn1(c1) > 0]; partial[blocks][2][C] = sum g, sum g*xhat
+// ReLU + BN backward statistics for bn1: g = dh * [bn1(c1) > 0]; partial[2][C][blocks] = sum g, sum g*xhat
 __global__ __launch_bounds__(256) void bn_relu_bwd_stats_kernel(const float* __restrict__ dh, const float* __restrict__ c1,
                                                                 const float* __restrict__ coeff,
                                                                 float* __restrict__ partial, long npos, int C,
@@ -671,26 +671,27 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_stats_kernel(const float* __r
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     float t = 0.f;
     for (int p = 0; p < planes; ++p) t += red[(long)p * 2 * C + i];
-    partial[(long)blockIdx.x * 2 * C + i] = t;
+    partial[(long)i * gridDim.x + blockIdx.x] = t;
   }
 }
 
-// sums the partial rows, writes dgamma/dbeta, s12 = [S1[C], S2[C]] and cb[3][C] = (scale, Q, R) with
-// d_x = [relu mask]*scale*dy + Q*x + R.  One wave per channel, lanes stride over the rows.
+// sums the partial rows ([2][C][rows]), writes dgamma/dbeta, s12 = [S1[C], S2[C]] and cb[3][C] = (scale, Q, R) with
+// d_x = [relu mask]*scale*dy + Q*x + R.  One workgroup per channel, threads stride over the contiguous rows.
 __global__ __launch_bounds__(256) void bn_bwd_coeff_kernel(const float* __restrict__ partial, int rows, double count,
                                                            const float* __restrict__ coeff, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, float* __restrict__ s12,
                                                            float* __restrict__ cb, int C, int training) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
+  __shared__ double red[16];
+  const int c = blockIdx.x;
+  const float* p1 = partial + (long)c * rows;
+  const float* p2 = partial + ((long)C + c) * rows;
   double s = 0.0, q = 0.0;
-  for (int r = lane; r < rows; r += 64) {
-    s += (double)partial[((long)r * 2) * C + c];
-    q += (double)partial[((long)r * 2 + 1) * C + c];
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    s += (double)p1[r];
+    q += (double)p2[r];
   }
-  const double S1 = wave_sum_d(s), S2 = wave_sum_d(q);
-  if (lane == 0) {
+  const double S1 = block_sum_d(s, red), S2 = block_sum_d(q, red + 8);
+  if (threadIdx.x == 0) {
     if (dgamma) dgamma[c] = (float)S2;
     if (dbeta) dbeta[c] = (float)S1;
     if (s12) { s12[c] = (float)S1; s12[C + c] = (float)S2; }
@@ -763,12 +764,12 @@ MMSA_EXPORT int mmsa_stem_bwd(const float* x, const float* w, const float* bias,
   MMSA_REQUIRE(B > 0 && H >= 2 && H % 2 == 0 && W >= 2 && W <= 1024);
   hipStream_t s = mmsa_stream(stream);
   const int rows = B * (H / 2);
-  float* p1 = scratch;                    // [rows][2][32]
+  float* p1 = scratch;                    // [2][32][rows]
   float* s12 = p1 + (long)rows * 64;      // [2][32]
   float* p2 = s12 + 64;                   // [rows][320]
   const size_t sh1 = (4 * (W + 2) + 8 * 2 * 32) * sizeof(float);
   hipLaunchKernelGGL(stem_bwd_stats_kernel, dim3(rows), dim3(256), sh1, s, x, w, bias, coeff, dout, p1, H, W);
-  hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(8), dim3(256), 0, s, p1, rows, (double)B * H * W, coeff, dgamma, dbeta,
+  hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(32), dim3(256), 0, s, p1, rows, (double)B * H * W, coeff, dgamma, dbeta,
                      s12, (float*)nullptr, 32, training);
   const size_t sh2 = (4 * (W + 2) + 8 * 320) * sizeof(float);
   const float inv_n = training ? 1.0f / ((float)B * H * W) : 0.f;
@@ -883,9 +884,18 @@ MMSA_EXPORT int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const f
   return mmsa_launch_status();
 }
 
+// positions per workgroup of the statistics pass: about 512 workgroups, whole passes of the position lanes
+static int bn_relu_bwd_pos_per_block(long npos, int C) {
+  const int planes = 1024 / C;
+  long ppb = (npos + 511) / 512;
+  ppb = (ppb + planes - 1) / planes * planes;
+  if (ppb > 256) ppb = 256;
+  return (int)ppb;
+}
+
 MMSA_EXPORT long mmsa_bn_relu_bwd_scratch_floats(long npos, int C) {
   if (npos <= 0 || C < 32 || C > 256 || C % 32) return MMSA_ERR_ARG;
-  const int pos_per_block = 256;
+  const int pos_per_block = bn_relu_bwd_pos_per_block(npos, C);
   const long blocks = (npos + pos_per_block - 1) / pos_per_block;
   return blocks * 2 * C + 3L * C;
 }
@@ -896,14 +906,14 @@ MMSA_EXPORT int mmsa_bn_relu_bwd(float* dh, const float* c1, const float* coeff,
   MMSA_REQUIRE(dh && c1 && coeff && dgamma && dbeta && scratch && npos > 0);
   MMSA_REQUIRE(C >= 32 && C <= 256 && C % 32 == 0);
   hipStream_t s = mmsa_stream(stream);
-  const int pos_per_block = 256;
+  const int pos_per_block = bn_relu_bwd_pos_per_block(npos, C);
   const int blocks = (int)((npos + pos_per_block - 1) / pos_per_block);
   float* partial = scratch;
   float* cb = scratch + (long)blocks * 2 * C;
   const int planes = 1024 / C;
   hipLaunchKernelGGL(bn_relu_bwd_stats_kernel, dim3(blocks), dim3(256), (size_t)planes * 2 * C * sizeof(float), s, dh,
                      c1, coeff, partial, npos, C, pos_per_block);
-  hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(mmsa_cdiv(C, 4)), dim3(256), 0, s, partial, blocks, (double)npos, coeff,
+  hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(C), dim3(256), 0, s, partial, blocks, (double)npos, coeff,
                      dgamma, dbeta, (float*)nullptr, cb, C, training);
   const long n4 = npos * (C / 4);
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dh, c1, coeff, cb, n4, C);

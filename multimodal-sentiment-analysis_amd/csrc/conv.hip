@@ -32,7 +32,10 @@ namespace {
 
 constexpr int MAX_TAPS = 9;
 constexpr int KC = 32;        // channels per K chunk
-constexpr int LDS_STRIDE = 36;  // floats per staged row (32 + 4 pad)
+#ifndef IGEMM_NBUF_VALUE
+#define IGEMM_NBUF_VALUE 5
+#endif
+constexpr int IGEMM_NBUF = IGEMM_NBUF_VALUE;   // LDS buffers of the forward / data-gradient kernel (chunks in flight + 2)
 
 struct ConvGeom {
   int B, H, W, Cin, Cout, ntaps;
@@ -89,8 +92,23 @@ struct ConvMulti {
   float* Y[4];
 };
 
+#ifdef MMSA_LAB_STAMPS
+// Diagnostic builds only (tools/igemm_lab.hip): per-workgroup clock stamps, written to a buffer of their own.
+__device__ unsigned long long* g_lab_stamps;
+#define LAB_STAMP(i)                                                                                   \
+  do {                                                                                                 \
+    if (threadIdx.x == 0 && g_lab_stamps) {                                                            \
+      const long wg_ = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;           \
+      g_lab_stamps[wg_ * 8 + (i)] = __builtin_amdgcn_s_memtime();                                      \
+      g_lab_stamps[wg_ * 8 + 4 + (i)] = __builtin_amdgcn_s_memrealtime();                              \
+    }                                                                                                  \
+  } while (0)
+#else
+#define LAB_STAMP(i)
+#endif
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool STATS, bool ACCUM>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict__ X, const float* __restrict__ Wp0,
+__global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict__ X, const float* __restrict__ Wp0,
                                                          float* __restrict__ Y0, float* __restrict__ stats,
                                                          const ConvGeom g, int tiles_per_img, const ConvMulti multi) {
   // kernel arguments are only read (never written: a modified by-value struct would be spilled to scratch)
@@ -98,18 +116,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
   const int ntaps = many ? multi.ntaps[blockIdx.z] : g.ntaps;
   const float* __restrict__ Wp = many ? multi.Wp[blockIdx.z] : Wp0;
   float* __restrict__ Y = many ? multi.Y[blockIdx.z] : Y0;
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(WAVES_M * WAVES_N == 4, "4 MFMA waves per workgroup (plus 4 loader waves)");
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;  // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold whole 32x32 MFMA tiles");
-  constexpr int A_LD = BM / 32;  // 16-byte loads per thread for the A tile (256 threads x 8 loads per row)
+  constexpr int A_LD = BM / 32;  // LDS-DMA instructions per wave and chunk for the A tile (8 rows = 1 KiB each)
   constexpr int B_LD = BN / 32;
-  constexpr int BUF_FLOATS = (BM + BN) * LDS_STRIDE;   // one LDS buffer: A rows then B rows of one 32-channel chunk
+  constexpr int LD = A_LD + B_LD;
+  constexpr int BUF_FLOATS = (BM + BN) * KC;   // one LDS buffer: A rows then B rows of one 32-channel chunk
+  constexpr int NBUF = IGEMM_NBUF;             // ring of LDS buffers; a chunk is requested NBUF-1 steps ahead
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  LAB_STAMP(0);
 
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
+  const int lane = t & 63;
+  // Waves 0-3 only read fragments from LDS and issue MFMAs; waves 4-7 only issue the global -> LDS requests.  A
+  // request instruction holds its wave for of the order of 100 cycles and the matrix pipe of that SIMD idles
+  // meanwhile unless another wave feeds it, so each SIMD hosts one wave of either kind.
+  const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool loader = wave8 >= 4;
+  const int wave = wave8 & 3;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int HW = g.H * g.W;
   const int b = blockIdx.x / tiles_per_img;
@@ -117,28 +144,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
   const int p0 = tile * BM;
   const int n0 = blockIdx.y * BN;
 
-  // Both operands are fetched through buffer descriptors: a byte offset past the end of the buffer reads as zero,
-  // which is how the taps that fall outside the image (and the rows past the end of the last tile) become zeros
-  // without any select on the loaded data (a select would force a wait for the load right where it is issued).
+  // Both operands go from global memory straight into LDS (buffer loads with the LDS destination: no staging
+  // registers, no LDS store instructions).  One wave instruction moves 8 rows x 128 bytes into 1 KiB of LDS in lane
+  // order, so the LDS image has unpadded 128-byte rows; bank conflicts of the 16-byte fragment reads are avoided by
+  // an XOR swizzle applied on the SOURCE side: slot s of row r holds the 16-byte piece s ^ ((r >> 1) & 7) of that
+  // row, and the fragment reads apply the same XOR.  A byte offset past the end of the buffer reads as zero, which
+  // is how taps outside the image, and rows past the end of the last tile, become zeros.
   const float* Xb = X + (long)b * HW * g.Cin;
   const __amdgpu_buffer_rsrc_t rX =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xb), 0, HW * g.Cin * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rW =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wp), 0, ntaps * g.Cout * g.Cin * 4, 0x00020000);
   constexpr int OOB = 0x7ffffff0;
+  typedef __attribute__((address_space(3))) void lds_void;
 
-  // Per-thread staging plan: byte offset of each A row inside the image and a bit mask of the taps whose source
-  // pixel lies inside the image.
-  const int c4 = t & 7;         // which 16-byte piece of the 32-channel chunk
-  const int rbase = t >> 3;     // 0..31
+  // Per-lane source plan: wave w fills row groups w, w+4, ... (8 rows each); lane l supplies row 8*group + (l >> 3),
+  // slot l & 7.
+  const int lrow = lane >> 3, lslot = lane & 7;
   int aoff[A_LD], boff[B_LD];
   unsigned amask[A_LD];
 #pragma unroll
   for (int j = 0; j < A_LD; ++j) {
-    const int p = p0 + rbase + 32 * j;
+    const int r = 8 * (wave + 4 * j) + lrow;
+    const int p = p0 + r;
     const bool ok = p < HW;
     const int h = p / g.W, w = p - h * g.W;
-    aoff[j] = (p * g.Cin + 4 * c4) * 4;
+    aoff[j] = (p * g.Cin + 4 * (lslot ^ ((r >> 1) & 7))) * 4;
     unsigned m = 0;
     for (int tp = 0; tp < ntaps; ++tp) {
       const int hh = h + g.dh[tp], ww = w + g.dw[tp];
@@ -147,43 +178,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
     amask[j] = m;
   }
 #pragma unroll
-  for (int j = 0; j < B_LD; ++j) boff[j] = ((n0 + rbase + 32 * j) * g.Cin + 4 * c4) * 4;
+  for (int j = 0; j < B_LD; ++j) {
+    const int r = 8 * (wave + 4 * j) + lrow;
+    boff[j] = ((n0 + r) * g.Cin + 4 * (lslot ^ ((r >> 1) & 7))) * 4;
+  }
   const int nchunks = ntaps * (g.Cin / KC);
 
-  // load cursor (uniform): which (tap, channel offset) the next global load fetches; it stops at the last chunk,
-  // so the trailing prefetches of the pipeline re-read that chunk harmlessly instead of branching.  The tap's
-  // offset is read one chunk before it is needed (ntoff), so the scalar load is never waited for.
-  int ltap = 0, lcin = 0, lcount = 0;
-  int ntoff = (g.dh[0] * g.W + g.dw[0]) * g.Cin * 4;
-  f32x4 ra[3][A_LD], rb[3][B_LD];
-  auto load_next = [&](f32x4(&qa)[A_LD], f32x4(&qb)[B_LD]) {
-    const int sa = lcin * 4;
-    const int sb = (ltap * g.Cout * g.Cin + lcin) * 4;
-#pragma unroll
-    for (int j = 0; j < A_LD; ++j) {
-      const int va = ((amask[j] >> ltap) & 1u) ? aoff[j] + ntoff : OOB;
-      qa[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rX, va, sa, 0));
+  // load cursor (uniform): which (tap, channel offset) the next request fetches; it stops at the last chunk, so the
+  // trailing requests of the pipeline re-read that chunk harmlessly instead of branching.  The tap's offset is read
+  // one chunk before it is needed (ntoff), so the scalar load is never waited for.
+  int ltap = 0, lcin = 0, lcount = 0, wbuf = 0;
+  int ndh = g.dh[0], ndw = g.dw[0];
+  // one LDS-DMA instruction of the current request: pieces 0 .. A_LD-1 are A rows, the rest B rows
+#ifndef MMSA_LAB_ABLATE
+#define MMSA_LAB_ABLATE 0   // diagnostic builds (tools/igemm_lab.hip) drop pipeline stages to price them
+#endif
+  auto request_piece = [&](int j) {
+    float* base = lds + wbuf * BUF_FLOATS + wave * 256;
+    if (MMSA_LAB_ABLATE & 16) {   // every lane out of range: the instruction issues, nothing is fetched
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void*)(base + j * 1024), 16, int(OOB), 0, 0, 0);
+      return;
     }
-#pragma unroll
-    for (int j = 0; j < B_LD; ++j)
-      qb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, boff[j], sb, 0));
+    if (j < A_LD) {
+      const int ntoff = (ndh * g.W + ndw) * g.Cin * 4;
+      const int va = ((amask[j] >> ltap) & 1u) ? aoff[j] + ntoff : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void*)(base + j * 1024), 16, int(va), int(lcin * 4), 0, 0);
+    } else {
+      const int sb = (ltap * g.Cout * g.Cin + lcin) * 4;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void*)(base + BM * KC + (j - A_LD) * 1024), 16,
+                                               int(boff[j - A_LD]), int(sb), 0, 0);
+    }
+  };
+  auto advance_cursor = [&]() {
+    wbuf = wbuf + 1 == NBUF ? 0 : wbuf + 1;
     if (lcount + 1 < nchunks) {   // uniform scalar bookkeeping
       ++lcount;
       lcin += KC;
       if (lcin == g.Cin) {
         lcin = 0;
         ++ltap;
-        ntoff = (g.dh[ltap] * g.W + g.dw[ltap]) * g.Cin * 4;
+        ndh = g.dh[ltap];
+        ndw = g.dw[ltap];
       }
     }
   };
-  auto store_chunk = [&](int buf, const f32x4(&qa)[A_LD], const f32x4(&qb)[B_LD]) {
-    float* base = lds + buf * BUF_FLOATS;
+  auto request_next = [&]() {
 #pragma unroll
-    for (int j = 0; j < A_LD; ++j) *reinterpret_cast<f32x4*>(base + (rbase + 32 * j) * LDS_STRIDE + 4 * c4) = qa[j];
-#pragma unroll
-    for (int j = 0; j < B_LD; ++j)
-      *reinterpret_cast<f32x4*>(base + (BM + rbase + 32 * j) * LDS_STRIDE + 4 * c4) = qb[j];
+    for (int j = 0; j < LD; ++j) request_piece(j);
+    advance_cursor();
   };
 
   f32x16 acc[TM][TN];
@@ -194,71 +236,93 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // Fragments of half a chunk (16 of its 32 channels): lane (li, lh) holds, per 8-channel group, the 4 consecutive
-  // channels 8*gk + 4*lh .. +3 of its row and feeds them to 4 successive MFMAs; A and B use the same permutation.
+  // Fragments of half a chunk (16 of its 32 channels): lane (li, lh) holds, per 8-channel group gk, the 4 consecutive
+  // channels 8*gk + 4*lh .. +3 of its row (piece 2*gk + lh) and feeds them to 4 successive MFMAs; A and B use the
+  // same permutation of k.
   const int li = lane & 31, lh = lane >> 5;
-  const int a_frag = (wm * WTM + li) * LDS_STRIDE + 4 * lh;
-  const int b_frag = (BM + wn * WTN + li) * LDS_STRIDE + 4 * lh;
+  const int swz = (li >> 1) & 7;
+  const int a_row = (wm * WTM + li) * KC;
+  const int b_row = BM * KC + (wn * WTN + li) * KC;
+  int piece[4];
+#pragma unroll
+  for (int gk = 0; gk < 4; ++gk) piece[gk] = 4 * ((2 * gk + lh) ^ swz);
   struct Frag {
     f32x4 a[2][TM], b[2][TN];
   };
   auto read_half = [&](Frag& f, int buf, int half) {
-    const float* Ab = lds + buf * BUF_FLOATS + a_frag + 16 * half;
-    const float* Bb = lds + buf * BUF_FLOATS + b_frag + 16 * half;
+    const float* Ab = lds + buf * BUF_FLOATS + a_row;
+    const float* Bb = lds + buf * BUF_FLOATS + b_row;
 #pragma unroll
     for (int gk = 0; gk < 2; ++gk) {
+      const int pc = piece[2 * half + gk];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) f.a[gk][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_STRIDE + 8 * gk);
+      for (int i = 0; i < TM; ++i) f.a[gk][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * KC + pc);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) f.b[gk][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_STRIDE + 8 * gk);
+      for (int j = 0; j < TN; ++j) f.b[gk][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * KC + pc);
     }
   };
-  auto mfma_half = [&](const Frag& f) {
+  // the MFMAs of one k pair (step s = 4*gk + e of a half chunk)
+  auto mfma_step = [&](const Frag& f, int s) {
+    const int gk = s >> 2, e = s & 3;
 #pragma unroll
-    for (int gk = 0; gk < 2; ++gk)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[gk][i][e], f.b[gk][j][e], acc[i][j], 0, 0, 0);
+  };
+  auto mfma_steps = [&](const Frag& f, int s_begin, int s_end) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[gk][i][e], f.b[gk][j][e], acc[i][j], 0, 0, 0);
+    for (int s = s_begin; s < s_end; ++s) {
+      mfma_step(f, s);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
 
-  // Pipeline (three register sets, three LDS buffers, one barrier per chunk).  At the top of the step for chunk ck:
-  // LDS holds chunks ck and ck+1, f0 holds the fragments of the first half of chunk ck, the register sets hold
-  // chunks ck+2 and ck+3.  The step issues the global loads of chunk ck+4, reads the second-half fragments, runs the
-  // first-half MFMAs, writes chunk ck+2 to LDS, reads the first-half fragments of chunk ck+1 and runs the
-  // second-half MFMAs: every LDS read has half a chunk of matrix work between its issue and its first use, and a
-  // global load has two chunks.
+  // Pipeline (ring of NBUF LDS buffers, one barrier per chunk).  At the top of the step for chunk ck: chunks ck and
+  // ck+1 are in LDS and visible, f0 holds the fragments of the first half of chunk ck, chunks ck+2 .. ck+NBUF-2 are
+  // on their way.  MFMA waves: first-half MFMAs (reading the second-half fragments behind the first of them), then
+  // second-half MFMAs (reading the first-half fragments of chunk ck+1 behind the first of them): every LDS read has
+  // half a chunk of matrix work between its issue and its first use.  Loader waves: request chunk ck+NBUF-1 into
+  // the buffer chunk ck-1 has left, then wait until at most the NBUF-3 youngest requests are outstanding (chunk
+  // ck+2 has landed).  Both then join the barrier that publishes chunk ck+2 and retires the reads of chunk ck.
   Frag f0, f1;
-  load_next(ra[0], rb[0]);
-  load_next(ra[1], rb[1]);
-  load_next(ra[2], rb[2]);
-  store_chunk(0, ra[0], rb[0]);
-  store_chunk(1, ra[1], rb[1]);
-  load_next(ra[0], rb[0]);
-  __syncthreads();
-  read_half(f0, 0, 0);
-  for (int base = 0; base < nchunks; base += 3) {
+  if (loader) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      if (base + u < nchunks) {   // uniform; false only in the last, partial round
-        load_next(ra[(u + 1) % 3], rb[(u + 1) % 3]);
-        read_half(f1, u, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_half(f0);
-        __builtin_amdgcn_sched_barrier(0);
-        store_chunk((u + 2) % 3, ra[(u + 2) % 3], rb[(u + 2) % 3]);
-        read_half(f0, (u + 1) % 3, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_half(f1);
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-      }
+    for (int i = 0; i < NBUF - 1; ++i) request_next();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 3) * LD) : "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int ck = 0; ck < nchunks; ++ck) {
+      if (!(MMSA_LAB_ABLATE & 1)) request_next();
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 3) * LD) : "memory");
+      if (!(MMSA_LAB_ABLATE & 4)) __builtin_amdgcn_s_barrier();
     }
+    // the trailing requests may still be writing LDS, which the statistics epilogue reuses
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __builtin_amdgcn_s_barrier();
+    read_half(f0, 0, 0);
+    LAB_STAMP(1);
+    int rbuf = 0;
+    for (int ck = 0; ck < nchunks; ++ck) {
+      const int rnext = rbuf + 1 == NBUF ? 0 : rbuf + 1;
+      // the LDS reads go out behind the first MFMA of each half: the matrix pipe is busy while they issue
+      mfma_steps(f0, 0, 1);
+      if (!(MMSA_LAB_ABLATE & 8)) read_half(f1, rbuf, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_steps(f0, 1, 8);
+      mfma_steps(f1, 0, 1);
+      if (!(MMSA_LAB_ABLATE & 8)) read_half(f0, rnext, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_steps(f1, 1, 8);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!(MMSA_LAB_ABLATE & 4)) __builtin_amdgcn_s_barrier();
+      rbuf = rnext;
+    }
+    __builtin_amdgcn_s_barrier();
   }
 
+  LAB_STAMP(2);
   // epilogue: D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* Yb = Y + (long)b * HW * g.Cout;
   float csum[TN], csq[TN];
@@ -273,7 +337,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
       for (int r = 0; r < 16; ++r) {
         const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int p = p0 + row;
-        if (p < HW) {
+        if (p < HW && !loader) {
           float v = acc[i][j][r];
           float* dst = Yb + (long)p * g.Cout + col;
           if (ACCUM) v += *dst;
@@ -292,7 +356,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
     for (int j = 0; j < TN; ++j) {
       csum[j] += __shfl_xor(csum[j], 32, 64);
       csq[j] += __shfl_xor(csq[j], 32, 64);
-      if (lh == 0) {
+      if (lh == 0 && !loader) {
         red[(wm * 2 + 0) * BN + wn * WTN + j * 32 + li] = csum[j];
         red[(wm * 2 + 1) * BN + wn * WTN + j * 32 + li] = csq[j];
       }
@@ -307,6 +371,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
       stats[((long)which * g.Cout + n0 + col) * gridDim.x + blockIdx.x] = s;
     }
   }
+  LAB_STAMP(3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -496,7 +561,7 @@ int fill_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout, int ntaps, co
 template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM>
 int launch_igemm_one(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int tiles, dim3 grid,
                      const ConvMulti& multi, hipStream_t s) {
-  constexpr size_t shmem = 3 * (size_t)(BM + BN) * LDS_STRIDE * sizeof(float);
+  constexpr size_t shmem = IGEMM_NBUF * (size_t)(BM + BN) * KC * sizeof(float);
   static bool attr_set = false;   // raising the dynamic-LDS limit is sticky per kernel; benign if raced
   if (shmem > 48 * 1024 && !attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM>),
@@ -504,7 +569,7 @@ int launch_igemm_one(const float* X, const float* Wp, float* Y, float* stats, co
       return MMSA_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM>), grid, dim3(256), shmem, s, X, Wp, Y,
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM>), grid, dim3(512), shmem, s, X, Wp, Y,
                      stats, g, tiles, multi);
   return mmsa_launch_status();
 }
