@@ -66,6 +66,11 @@ MMSA_API int mmsa_conv_tile_rows(int B, int H, int W, int Cout);
  * dh/dw are host arrays.  stats (optional): [2][Cout][B*tiles] per-tile column sums and sums of squares. */
 MMSA_API int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* stats, int B, int H, int W, int Cin,
                            int Cout, int ntaps, const int* dh_host, const int* dw_host, int accumulate, void* stream);
+/* Y = conv(X, Wp) + X2 . Wp2 in one launch (X2 [B,H,W,Cin], Wp2 [Cout][Cin]): the data gradient of a residual block's
+ * input, 3x3 branch plus 1x1 shortcut (autograd of multimodal_model.py:64-70) */
+MMSA_API int mmsa_conv_fwd_dual(const float* X, const float* Wp, const float* X2, const float* Wp2, float* Y, int B,
+                                int H, int W, int Cin, int Cout, int ntaps, const int* dh_host, const int* dw_host,
+                                void* stream);
 /* n (<= 4) convolutions of one input in one launch (the text branch's filter widths): problem i uses Wp_host[i],
  * the first ntaps_host[i] entries of the offset table and writes Y_host[i]; multimodal_model.py:186-188 */
 MMSA_API int mmsa_conv_fwd_multi(const float* X, const float* const* Wp_host, float* const* Y_host,

@@ -39,7 +39,7 @@ constexpr int IGEMM_NBUF = IGEMM_NBUF_VALUE;   // LDS buffers of the forward / d
 
 struct ConvGeom {
   int B, H, W, Cin, Cout, ntaps;
-  int dh[MAX_TAPS], dw[MAX_TAPS];
+  int dh[MAX_TAPS + 1], dw[MAX_TAPS + 1];   // entries past ntaps are zero (the optional second operand's centre tap)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -90,6 +90,10 @@ struct ConvMulti {
   int ntaps[4];
   const float* Wp[4];
   float* Y[4];
+  // optional second operand pair appended to the K loop: Y += X2[b, p, :] . Wp2[:, :] (a 1x1 convolution of another
+  // tensor with the same channel count, e.g. the shortcut's data gradient next to the 3x3 one)
+  const float* X2;
+  const float* Wp2;
 };
 
 #ifdef MMSA_LAB_STAMPS
@@ -155,6 +159,12 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xb), 0, HW * g.Cin * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t rW =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wp), 0, ntaps * g.Cout * g.Cin * 4, 0x00020000);
+  const bool dual = multi.X2 != nullptr;   // uniform
+  const float* X2b = dual ? multi.X2 + (long)b * HW * g.Cin : Xb;
+  const __amdgpu_buffer_rsrc_t rX2 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X2b), 0, HW * g.Cin * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(dual ? multi.Wp2 : Wp), 0, g.Cout * g.Cin * 4, 0x00020000);
   constexpr int OOB = 0x7ffffff0;
   typedef __attribute__((address_space(3))) void lds_void;
 
@@ -175,6 +185,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
       const int hh = h + g.dh[tp], ww = w + g.dw[tp];
       if (ok && hh >= 0 && hh < g.H && ww >= 0 && ww < g.W) m |= 1u << tp;
     }
+    if (ok) m |= 1u << ntaps;   // the second operand's centre tap
     amask[j] = m;
   }
 #pragma unroll
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
     const int r = 8 * (wave + 4 * j) + lrow;
     boff[j] = ((n0 + r) * g.Cin + 4 * (lslot ^ ((r >> 1) & 7))) * 4;
   }
-  const int nchunks = ntaps * (g.Cin / KC);
+  const int nchunks = (ntaps + (dual ? 1 : 0)) * (g.Cin / KC);
 
   // load cursor (uniform): which (tap, channel offset) the next request fetches; it stops at the last chunk, so the
   // trailing requests of the pipeline re-read that chunk harmlessly instead of branching.  The tap's offset is read
@@ -199,14 +210,23 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void*)(base + j * 1024), 16, int(OOB), 0, 0, 0);
       return;
     }
+    const bool second = ltap >= ntaps;   // uniform
     if (j < A_LD) {
       const int ntoff = (ndh * g.W + ndw) * g.Cin * 4;
       const int va = ((amask[j] >> ltap) & 1u) ? aoff[j] + ntoff : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void*)(base + j * 1024), 16, int(va), int(lcin * 4), 0, 0);
+      if (second)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lds_void*)(base + j * 1024), 16, int(va), int(lcin * 4), 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void*)(base + j * 1024), 16, int(va), int(lcin * 4), 0, 0);
     } else {
-      const int sb = (ltap * g.Cout * g.Cin + lcin) * 4;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void*)(base + BM * KC + (j - A_LD) * 1024), 16,
-                                               int(boff[j - A_LD]), int(sb), 0, 0);
+      if (second) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, (lds_void*)(base + BM * KC + (j - A_LD) * 1024), 16,
+                                                 int(boff[j - A_LD]), int(lcin * 4), 0, 0);
+      } else {
+        const int sb = (ltap * g.Cout * g.Cin + lcin) * 4;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void*)(base + BM * KC + (j - A_LD) * 1024), 16,
+                                                 int(boff[j - A_LD]), int(sb), 0, 0);
+      }
     }
   };
   auto advance_cursor = [&]() {
@@ -551,7 +571,7 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout, int ntaps) {
 int fill_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout, int ntaps, const int* dh, const int* dw) {
   if (ntaps < 1 || ntaps > MAX_TAPS) return MMSA_ERR_ARG;
   g.B = B; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout; g.ntaps = ntaps;
-  for (int i = 0; i < MAX_TAPS; ++i) {
+  for (int i = 0; i <= MAX_TAPS; ++i) {
     g.dh[i] = i < ntaps ? dh[i] : 0;
     g.dw[i] = i < ntaps ? dw[i] : 0;
   }
@@ -642,6 +662,26 @@ MMSA_EXPORT int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* 
   return launch_igemm<64, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, ConvMulti{}, s);
 }
 
+// Y[B,H,W,Cout] = conv(X, Wp) + X2 . Wp2 in one launch: X2 [B,H,W,Cin] is a second input with the same channel count
+// and Wp2 [Cout][Cin] its 1x1 weights (e.g. the data gradient of a residual block's input: the 3x3 branch plus the
+// 1x1 shortcut).
+MMSA_EXPORT int mmsa_conv_fwd_dual(const float* X, const float* Wp, const float* X2, const float* Wp2, float* Y, int B,
+                                   int H, int W, int Cin, int Cout, int ntaps, const int* dh, const int* dw,
+                                   void* stream) {
+  MMSA_REQUIRE(X && Wp && X2 && Wp2 && Y && dh && dw);
+  MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+  MMSA_REQUIRE(Cin % KC == 0 && Cout % 32 == 0);
+  ConvGeom g;
+  if (fill_geom(g, B, H, W, Cin, Cout, ntaps, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
+  hipStream_t s = mmsa_stream(stream);
+  ConvMulti m{};
+  m.X2 = X2;
+  m.Wp2 = Wp2;
+  if (Cout % 64 != 0) return launch_igemm<128, 32, 4, 1>(X, Wp, Y, nullptr, g, 0, m, s);
+  if (pick_bm(B, H, W, Cout) == 128) return launch_igemm<128, 64, 2, 2>(X, Wp, Y, nullptr, g, 0, m, s);
+  return launch_igemm<64, 64, 2, 2>(X, Wp, Y, nullptr, g, 0, m, s);
+}
+
 // n (<= 4) convolutions of the same input X in one launch: problem i uses packed weights Wp[i] ([ntaps[i]][Cout][Cin]),
 // the first ntaps[i] entries of the shared offset table and writes Y[i] ([B,H,W,Cout]).  Wp / Y / ntaps are host arrays.
 MMSA_EXPORT int mmsa_conv_fwd_multi(const float* X, const float* const* Wp, float* const* Y, const int* ntaps, int n,
@@ -649,7 +689,7 @@ MMSA_EXPORT int mmsa_conv_fwd_multi(const float* X, const float* const* Wp, floa
   MMSA_REQUIRE(X && Wp && Y && ntaps && dh && dw && n >= 1 && n <= 4);
   MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % KC == 0 && Cout % 64 == 0);
   int maxt = 0;
-  ConvMulti m;
+  ConvMulti m{};
   m.n = n;
   for (int i = 0; i < 4; ++i) {
     m.ntaps[i] = i < n ? ntaps[i] : 0;

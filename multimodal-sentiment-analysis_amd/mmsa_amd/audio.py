@@ -158,8 +158,8 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
     if not need_dx:
         return None
     d_in = ws.buf(name + ".d_in", (B, H, W, Cin))
-    ops.conv_fwd(d_c1, s.w1d, d_in, None, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
-    ops.conv_fwd(d_sc, s.wsd, d_in, None, B, H, W, Cout, Cin, ops.TAPS1X1, negate=True, accumulate=True)
+    # 3x3 branch and 1x1 shortcut in one launch (one K loop over both operand pairs)
+    ops.conv_fwd_dual(d_c1, s.w1d, d_sc, s.wsd, d_in, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
     return d_in
 
 

@@ -159,6 +159,22 @@ def conv_fwd(X, Wp, Y, stats, B, H, W, Cin, Cout, taps, negate=False, accumulate
         ev.record()
 
 
+def conv_fwd_dual(X, Wp, X2, Wp2, Y, B, H, W, Cin, Cout, taps, negate=False):
+    """Y = conv(X, Wp) + (1x1) X2 . Wp2 in one launch; X2 has the channel count of X."""
+    if (X.numel() != B * H * W * Cin or X2.numel() != X.numel() or Y.numel() != B * H * W * Cout
+            or Wp.numel() != len(taps) * Cin * Cout or Wp2.numel() != Cin * Cout):
+        raise ValueError("conv_fwd_dual: operand sizes do not match the geometry")
+    sgn = -1 if negate else 1
+    ev = None
+    if PROFILE is not None:
+        bm, bn = (128, 32) if Cout % 64 else (conv_tile_rows(B, H, W, Cout), 64)
+        ev = _prof_begin(_igemm_name(bm, bn, False, False), 2.0 * B * H * W * Cin * Cout * (len(taps) + 1))
+    _lib.call("mmsa_conv_fwd_dual", _chk(X), _chk(Wp), _chk(X2), _chk(Wp2), _chk(Y), B, H, W, Cin, Cout, len(taps),
+              _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), _stream())
+    if ev is not None:
+        ev.record()
+
+
 def conv_fwd_multi(X, Wps, Ys, ntaps_list, B, H, W, Cin, Cout, taps):
     """Several convolutions of X in one launch; problem i uses the first ntaps_list[i] offsets of ``taps``."""
     if X.numel() != B * H * W * Cin or len(Wps) != len(Ys) or len(Wps) != len(ntaps_list) or len(Wps) > 4:

@@ -147,6 +147,13 @@ def test_conv1x1_and_dgrad(B, H, W, Cin, Cout):
     xr.grad = None
     F.conv2d(xr, w1.double()).backward(dy.double())
     check(nchw(dx.cpu()), ref3 + xr.grad, 2e-6)
+    # the same sum in one launch, with a different second gradient tensor (as in a residual block)
+    dy2 = torch.randn(B, Cout, H, W, generator=g)
+    dx2 = torch.empty(B, H, W, Cin, device=DEV)
+    ops.conv_fwd_dual(dyd, wd3, nhwc(dy2).to(DEV), wd1, dx2, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
+    xr.grad = None
+    F.conv2d(xr, w1.double()).backward(dy2.double())
+    check(nchw(dx2.cpu()), ref3 + xr.grad, 2e-6)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 32, 65, 32, 64), (3, 32, 65, 64, 64), (2, 16, 32, 64, 128),
