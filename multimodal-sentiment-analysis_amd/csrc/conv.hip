@@ -431,7 +431,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+#ifdef MMSA_LAB_STAMPS
+  unsigned long long lab_t0 = __builtin_amdgcn_s_memtime(), lab_load = 0, lab_comp = 0, lab_t;
+  const unsigned long long lab_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int strip = blockIdx.y; strip < nstrips; strip += gridDim.y) {
+#ifdef MMSA_LAB_STAMPS
+    lab_t = __builtin_amdgcn_s_memtime();
+#endif
     const int b = strip / strips_per_img;
     const int r0 = (strip - b * strips_per_img) * R;
     __syncthreads();  // the previous strip's reads are done
@@ -455,6 +462,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
       *reinterpret_cast<f32x4*>(Ys + (long)i * 4) = v;
     }
     __syncthreads();
+#ifdef MMSA_LAB_STAMPS
+    { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); lab_load += n_ - lab_t; lab_t = n_; }
+#endif
     // One MFMA step covers two positions (k = lane half).  Operands of step s+1 are read from LDS before the MFMAs
     // of step s issue, so the LDS latency hides behind the matrix pipe.  For odd W the last step's second
     // position does not exist: its dY operand is zero and its X address is clamped.
@@ -486,8 +496,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
         for (int i = 0; i < MAXT; ++i) a[i] = na[i];
       }
     }
+#ifdef MMSA_LAB_STAMPS
+    { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); lab_comp += n_ - lab_t; }
+#endif
   }
 
+#ifdef MMSA_LAB_STAMPS
+  const unsigned long long lab_t2 = __builtin_amdgcn_s_memtime();
+#endif
   const int slab = NT == 1 ? (int)blockIdx.y * 2 + q : (int)blockIdx.y;
   float* out = partial + (long)slab * NT * g.Cin * g.Cout;
 #pragma unroll
@@ -500,6 +516,17 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
         out[((long)tap * g.Cin + ci) * g.Cout + cout0 + jt * 32 + li] = acc[i][r];      // D col = lane & 31
       }
     }
+#ifdef MMSA_LAB_STAMPS
+  if (threadIdx.x == 0 && g_lab_stamps) {
+    const long wg_ = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    g_lab_stamps[wg_ * 8 + 0] = lab_load;
+    g_lab_stamps[wg_ * 8 + 1] = lab_comp;
+    g_lab_stamps[wg_ * 8 + 2] = __builtin_amdgcn_s_memtime() - lab_t2;
+    g_lab_stamps[wg_ * 8 + 3] = __builtin_amdgcn_s_memtime() - lab_t0;
+    g_lab_stamps[wg_ * 8 + 4] = lab_r0;
+    g_lab_stamps[wg_ * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // partial[slab][tap][Cin][Cout] -> dW[Cout][Cin][ntaps]  (+= when accumulate).  64 outputs per workgroup, the

@@ -17,6 +17,8 @@ from .workspace import Grads, Workspace
 
 
 _SIDE_STREAMS = {}
+import os as _os
+FORK_WGRAD = _os.environ.get("MMSA_FORK_WGRAD", "1") != "0"
 
 
 def side_stream(device, which: int = 0) -> torch.cuda.Stream:
@@ -36,8 +38,8 @@ class fork:
     fork: their buffers are never freed, so no allocator bookkeeping across streams is needed; with throw-away
     buffers (autograd path) everything stays on one stream."""
 
-    def __init__(self, ws, device, which: int = 0):
-        self.side = side_stream(device, which) if ws.persistent else None
+    def __init__(self, ws, device, which: int = 0, enable: bool = True):
+        self.side = side_stream(device, which) if ws.persistent and enable else None
         self.ctx = None
 
     def __enter__(self):
@@ -144,7 +146,7 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
     wg = ws.buf(name + ".wgrad_ws", wsz)
     # The three weight gradients feed nothing but the optimiser: they run on a helper stream while the data
     # gradient chain (the critical path into the previous block) continues on the main stream.
-    with fork(ws, d_out.device):                 # d_c2 / d_sc are ready
+    with fork(ws, d_out.device, enable=FORK_WGRAD):                 # d_c2 / d_sc are ready
         ops.conv_wgrad(s.h1, d_c2, grads.of(blk.conv2.weight), wg, B, H, W, Cout, Cout, ops.TAPS3X3)
         ops.conv_wgrad(s.a_in, d_sc, grads.of(blk.shortcut[0].weight), wg, B, H, W, Cin, Cout, ops.TAPS1X1)
     d_h1 = ws.buf(name + ".d_h1", (B, H, W, Cout))
@@ -153,7 +155,7 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
     ops.bn_relu_bwd(d_h1, s.c1, s.coeff1, grads.of(blk.bn1.weight), grads.of(blk.bn1.bias), sc2, B * H * W, Cout,
                     training)
     d_c1 = d_h1
-    with fork(ws, d_out.device):                 # d_c1 is ready
+    with fork(ws, d_out.device, enable=FORK_WGRAD):                 # d_c1 is ready
         ops.conv_wgrad(s.a_in, d_c1, grads.of(blk.conv1.weight), wg, B, H, W, Cin, Cout, ops.TAPS3X3)
     if not need_dx:
         return None
