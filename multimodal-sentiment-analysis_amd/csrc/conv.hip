@@ -413,7 +413,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
   float* Ys = lds + (R + 2) * WP * 32;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 31, kk = lane >> 5;
-  const int jt = wave & 1, q = wave >> 1;
+  // 3x3: the two tap groups hold 5 and 4 taps.  Two workgroups share a CU; the second swaps the groups between its
+  // wave pairs, so that (with the usual wave -> SIMD placement) every SIMD hosts one 5-tap and one 4-tap wave.
+  const int swap = NT == 1 ? 0 : (int)(((blockIdx.y * gridDim.x + blockIdx.x) >> 8) & 1);
+  const int jt = wave & 1, q = (wave >> 1) ^ swap;
   const int cgroups = g.Cout / 64;
   const int cin0 = (blockIdx.x / cgroups) * 32;
   const int cout0 = (blockIdx.x % cgroups) * 64;
@@ -442,24 +445,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
     const int b = strip / strips_per_img;
     const int r0 = (strip - b * strips_per_img) * R;
     __syncthreads();  // the previous strip's reads are done
+    // staging in batches of eight independent 16-byte loads per thread, so that one round trip to memory covers
+    // eight pieces instead of one
     const float* Xb = X + (long)b * g.H * g.W * g.Cin + cin0;
-    for (int i = t; i < (R + 2) * WP * 8; i += 256) {
-      const int c4 = i & 7, pc = i >> 3;
-      const int row = pc / WP, col = pc - row * WP;
-      const int h = r0 - 1 + row, w = col - 1;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (h >= 0 && h < g.H && w >= 0 && w < g.W)
-        v = *reinterpret_cast<const f32x4*>(Xb + ((long)h * g.W + w) * g.Cin + 4 * c4);
-      *reinterpret_cast<f32x4*>(Xs + (long)i * 4) = v;
+    const int nx = (R + 2) * WP * 8;
+    for (int i0 = t; i0 < nx; i0 += 256 * 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        const int c4 = i & 7, pc = i >> 3;
+        const int row = pc / WP, col = pc - row * WP;
+        const int h = r0 - 1 + row, w = col - 1;
+        v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < nx && h >= 0 && h < g.H && w >= 0 && w < g.W)
+          v[u] = *reinterpret_cast<const f32x4*>(Xb + ((long)h * g.W + w) * g.Cin + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        if (i < nx) *reinterpret_cast<f32x4*>(Xs + (long)i * 4) = v[u];
+      }
     }
     const float* Yb = dY + (long)b * g.H * g.W * g.Cout + cout0;
-    for (int i = t; i < R * g.W * 16; i += 256) {
-      const int c4 = i & 15, pc = i >> 4;
-      const int row = pc / g.W, w = pc - row * g.W;
-      const int h = r0 + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (h < g.H) v = *reinterpret_cast<const f32x4*>(Yb + ((long)h * g.W + w) * g.Cout + 4 * c4);
-      *reinterpret_cast<f32x4*>(Ys + (long)i * 4) = v;
+    const int ny = R * g.W * 16;
+    for (int i0 = t; i0 < ny; i0 += 256 * 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        const int c4 = i & 15, pc = i >> 4;
+        const int row = pc / g.W, w = pc - row * g.W;
+        const int h = r0 + row;
+        v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < ny && h < g.H) v[u] = *reinterpret_cast<const f32x4*>(Yb + ((long)h * g.W + w) * g.Cout + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        if (i < ny) *reinterpret_cast<f32x4*>(Ys + (long)i * 4) = v[u];
+      }
     }
     __syncthreads();
 #ifdef MMSA_LAB_STAMPS
@@ -530,28 +555,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
 }
 
 // partial[slab][tap][Cin][Cout] -> dW[Cout][Cin][ntaps]  (+= when accumulate).  64 outputs per workgroup, the
-// four waves take interleaved slabs (independent loads, unrolled) and are combined in fixed order through LDS.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW,
-                                                           int nslabs, int ntaps, int Cin, int Cout, int accumulate) {
-  __shared__ float red[4][64];
+// NW (4 or 16, by the number of slabs) waves take interleaved slabs (four independent loads each per round) and are combined in fixed order
+// through LDS.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW,
+                                                               int nslabs, int ntaps, int Cin, int Cout, int accumulate) {
+  __shared__ float red[NW][64];
   const long total = (long)ntaps * Cin * Cout;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long i = (long)blockIdx.x * 64 + lane;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < total) {
     int k = w;
-    for (; k + 12 < nslabs; k += 16) {
+    for (; k + 3 * NW < nslabs; k += 4 * NW) {
       s0 += partial[(long)k * total + i];
-      s1 += partial[(long)(k + 4) * total + i];
-      s2 += partial[(long)(k + 8) * total + i];
-      s3 += partial[(long)(k + 12) * total + i];
+      s1 += partial[(long)(k + NW) * total + i];
+      s2 += partial[(long)(k + 2 * NW) * total + i];
+      s3 += partial[(long)(k + 3 * NW) * total + i];
     }
-    for (; k < nslabs; k += 4) s0 += partial[(long)k * total + i];
+    for (; k < nslabs; k += NW) s0 += partial[(long)k * total + i];
   }
   red[w][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (w == 0 && i < total) {
-    const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) s += red[k][lane];
     const int co = (int)(i % Cout);
     const long r = i / Cout;
     const int ci = (int)(r % Cin);
@@ -792,7 +821,11 @@ MMSA_EXPORT int mmsa_conv_wgrad_reduce(const float* workspace, float* dW, int B,
   MMSA_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0 && (ntaps == 1 || ntaps == 9));
   const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, ntaps);
   const long total = (long)ntaps * Cin * Cout;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, mmsa_stream(stream),
-                     workspace, dW, p.nslabs, ntaps, Cin, Cout, accumulate);
+  if (p.nslabs > 64)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0,
+                       mmsa_stream(stream), workspace, dW, p.nslabs, ntaps, Cin, Cout, accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, mmsa_stream(stream),
+                       workspace, dW, p.nslabs, ntaps, Cin, Cout, accumulate);
   return mmsa_launch_status();
 }
