@@ -19,7 +19,7 @@ constexpr int NFFT = 1024;
 constexpr int HOP = 512;
 constexpr int NBINS = 513;
 constexpr int NMEL = 64;
-constexpr int FPB = 5;  // frames per workgroup
+constexpr int FPB = 2;  // frames per workgroup (short workgroups: the launch is latency-bound at small batches)
 
 __global__ __launch_bounds__(256) void logmel_db_kernel(
     const float* __restrict__ wave, long wave_stride, int n_valid, int n_target, int n_frames,
@@ -35,8 +35,10 @@ __global__ __launch_bounds__(256) void logmel_db_kernel(
   __shared__ float2 fb[512];
   __shared__ float power[NBINS + 3];
   __shared__ float dbv[NMEL][FPB + 1];
+  __shared__ float2 tws[256];   // stage twiddles: read once instead of once per butterfly stage
 
   const int t = threadIdx.x;
+  tws[t] = make_float2(tw512[2 * t], tw512[2 * t + 1]);
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * FPB;
   const float* w = wave + (long)b * wave_stride;
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void logmel_db_kernel(
       const int k = t & (p - 1);
       const int j = ((t - k) << 1) + k;
       const int ti = k * (256 / p);
-      const float c = tw512[2 * ti], sn = tw512[2 * ti + 1];
+      const float c = tws[ti].x, sn = tws[ti].y;
       const float2 u0 = x[t];
       const float2 v = x[t + 256];
       const float2 u1 = make_float2(v.x * c - v.y * sn, v.x * sn + v.y * c);
@@ -113,14 +115,14 @@ __global__ __launch_bounds__(256) void logmel_db_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void logmel_norm_kernel(float* __restrict__ io, int n_elem, float top_db) {
+__global__ __launch_bounds__(1024) void logmel_norm_kernel(float* __restrict__ io, int n_elem, float top_db) {
   extern __shared__ float vals[];
   __shared__ float redf[16];
   __shared__ double redd[16];
   const int t = threadIdx.x;
   float* p = io + (long)blockIdx.x * n_elem;
   float mx = -INFINITY;
-  for (int i = t; i < n_elem; i += 256) {
+  for (int i = t; i < n_elem; i += 1024) {
     const float v = p[i];
     vals[i] = v;
     mx = fmaxf(mx, v);
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256) void logmel_norm_kernel(float* __restrict__ io
   mx = block_max(mx, redf);
   const float floor_v = mx - top_db;
   double s = 0.0;
-  for (int i = t; i < n_elem; i += 256) {
+  for (int i = t; i < n_elem; i += 1024) {
     const float v = fmaxf(vals[i], floor_v);
     vals[i] = v;
     s += (double)v;
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void logmel_norm_kernel(float* __restrict__ io
   s = block_sum_d(s, redd);
   const double mean = s / (double)n_elem;
   double q = 0.0;
-  for (int i = t; i < n_elem; i += 256) {
+  for (int i = t; i < n_elem; i += 1024) {
     const double d = (double)vals[i] - mean;
     q += d * d;
   }
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void logmel_norm_kernel(float* __restrict__ io
   const float meanf = (float)mean;
   const float stdf = (float)sqrt(q / (double)(n_elem - 1));
   const float denom = stdf + 1e-8f;
-  for (int i = t; i < n_elem; i += 256) {
+  for (int i = t; i < n_elem; i += 1024) {
     float v = (vals[i] - meanf) / denom;
     v = fminf(fmaxf(v, -6.f), 6.f);
     if (!(fabsf(v) <= 6.f)) v = 0.f;  // NaN scrub (Inf cannot survive the clamp)
@@ -184,7 +186,7 @@ MMSA_EXPORT int mmsa_logmel_fwd(const float* wave, long wave_stride, int n_valid
   dim3 grid(mmsa_cdiv(n_frames, FPB), batch);
   hipLaunchKernelGGL(logmel_db_kernel, grid, dim3(256), 0, mmsa_stream(stream), wave, wave_stride, n_valid, n_target,
                      n_frames, window, tw512, tw1024, melfb, melrange, out);
-  hipLaunchKernelGGL(logmel_norm_kernel, dim3(batch), dim3(256), n_elem * sizeof(float), mmsa_stream(stream), out,
+  hipLaunchKernelGGL(logmel_norm_kernel, dim3(batch), dim3(1024), n_elem * sizeof(float), mmsa_stream(stream), out,
                      n_elem, top_db);
   return mmsa_launch_status();
 }
