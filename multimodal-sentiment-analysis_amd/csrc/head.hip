@@ -58,14 +58,27 @@ __device__ __forceinline__ void matvec(const float* __restrict__ W, const float*
     const float* wa = W + (long)min(na, N - 1) * K;
     const float* wb = W + (long)min(nb, N - 1) * K;
     float a = 0.f, b = 0.f;
-    for (int k = 4 * sub; k < K; k += 4 * LPR) {
-      const f32x4 x4 = *reinterpret_cast<const f32x4*>(x + k);
-      const f32x4 u = *reinterpret_cast<const f32x4*>(wa + k);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(wb + k);
+    // all of a row pair's pieces are requested before any is used (K <= 512: at most 8 steps): one round trip to
+    // memory per pass instead of one per step
+    // (loads are unconditional, from a clamped offset: a load under a run-time condition would be waited for
+    // on its own)
+    f32x4 u[8], v[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int k = min(4 * sub + it * 4 * LPR, K - 4);
+      u[it] = *reinterpret_cast<const f32x4*>(wa + k);
+      v[it] = *reinterpret_cast<const f32x4*>(wb + k);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int k = 4 * sub + it * 4 * LPR;
+      const bool in = k < K;
+      const f32x4 x4 = *reinterpret_cast<const f32x4*>(x + (in ? k : 0));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        a = fmaf(u[e], x4[e], a);
-        b = fmaf(v[e], x4[e], b);
+        const float xe = in ? x4[e] : 0.f;
+        a = fmaf(u[it][e], xe, a);
+        b = fmaf(v[it][e], xe, b);
       }
     }
 #pragma unroll
@@ -90,14 +103,20 @@ __device__ __forceinline__ void matvec_t(const float* __restrict__ W, const floa
   const int kl = t % Kp, grp = t / Kp;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (kl < K && grp < G) {
-    int n = grp;
-    for (; n + 3 * G < N; n += 4 * G) {
-      a0 = fmaf(g[n], W[(long)n * K + kl], a0);
-      a1 = fmaf(g[n + G], W[(long)(n + G) * K + kl], a1);
-      a2 = fmaf(g[n + 2 * G], W[(long)(n + 2 * G) * K + kl], a2);
-      a3 = fmaf(g[n + 3 * G], W[(long)(n + 3 * G) * K + kl], a3);
+    // sixteen independent weight loads in flight per thread
+    for (int n0 = grp; n0 < N; n0 += 16 * G) {
+      float wv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) wv[i] = W[(long)min(n0 + i * G, N - 1) * K + kl];   // unconditional loads
+#pragma unroll
+      for (int i = 0; i < 16; i += 4) {
+        const int n = n0 + i * G;
+        a0 = fmaf(n < N ? g[n] : 0.f, wv[i], a0);
+        a1 = fmaf(n + G < N ? g[n + G] : 0.f, wv[i + 1], a1);
+        a2 = fmaf(n + 2 * G < N ? g[n + 2 * G] : 0.f, wv[i + 2], a2);
+        a3 = fmaf(n + 3 * G < N ? g[n + 3 * G] : 0.f, wv[i + 3], a3);
+      }
     }
-    for (; n < N; n += G) a0 = fmaf(g[n], W[(long)n * K + kl], a0);
   }
   __syncthreads();   // the previous user of `part` is done
   part[t] = (a0 + a1) + (a2 + a3);
@@ -110,25 +129,31 @@ __device__ __forceinline__ void matvec_t(const float* __restrict__ W, const floa
   __syncthreads();
 }
 
-// mean and 1/sqrt(var + eps) of v[0..N) (LDS), two passes as torch's LayerNorm
-__device__ __forceinline__ void row_stats(const float* v, int N, float* red, float& mean, float& rstd) {
+// Sum of v[0..N) (LDS) computed by every wave for itself (lanes stride over the row, then a wave reduction): all
+// waves obtain the same value in the same order of operations and no workgroup barrier is needed.
+__device__ __forceinline__ float wave_row_sum(const float* v, int N) {
   float s = 0.f;
-  for (int n = threadIdx.x; n < N; n += HT) s += v[n];
-  mean = block_sum(s, red) / (float)N;
+  for (int n = threadIdx.x & 63; n < N; n += 64) s += v[n];
+  return wave_sum(s);
+}
+
+// mean and 1/sqrt(var + eps) of v[0..N) (LDS), two passes as torch's LayerNorm, wave-redundant
+__device__ __forceinline__ void row_stats(const float* v, int N, float& mean, float& rstd) {
+  mean = wave_row_sum(v, N) / (float)N;
   float q = 0.f;
-  for (int n = threadIdx.x; n < N; n += HT) {
+  for (int n = threadIdx.x & 63; n < N; n += 64) {
     const float d = v[n] - mean;
     q = fmaf(d, d, q);
   }
-  rstd = 1.0f / sqrtf(block_sum(q, red) / (float)N + LN_EPS);
+  rstd = 1.0f / sqrtf(wave_sum(q) / (float)N + LN_EPS);
 }
 
 // y = dropout(relu(LN(pre) * gamma + beta)); pre (LDS) is also stored to HBM with its statistics
 __device__ __forceinline__ void ln_relu_drop(const float* pre, int N, const float* __restrict__ gamma,
                                              const float* __restrict__ beta, float* y_lds, float* y_g, float* pre_g,
-                                             float* stats_g, int b, float drop_p, unsigned long long seed, float* red) {
+                                             float* stats_g, int b, float drop_p, unsigned long long seed) {
   float mean, rstd;
-  row_stats(pre, N, red, mean, rstd);
+  row_stats(pre, N, mean, rstd);
   if (threadIdx.x == 0) {
     stats_g[2 * b] = mean;
     stats_g[2 * b + 1] = rstd;
@@ -146,15 +171,19 @@ __device__ __forceinline__ void ln_relu_drop(const float* pre, int N, const floa
 }
 
 // gradient through dropout, ReLU and LayerNorm of one Linear+LN+ReLU layer: d (LDS, gradient w.r.t. the layer output)
-// -> g (LDS, gradient w.r.t. the linear output); dLn and dPre rows go to HBM for the parameter-gradient kernel
-__device__ __forceinline__ void ln_relu_drop_bwd(const float* d_in, float* g, int N, const float* __restrict__ pre_g,
-                                                 const float* __restrict__ stats_g, const float* __restrict__ gamma,
-                                                 const float* __restrict__ beta, float* dln_g, float* dpre_g, int b,
-                                                 float drop_p, unsigned long long seed, float* red) {
+// -> g (LDS, gradient w.r.t. the linear output); dLn and dPre rows go to HBM for the parameter-gradient kernel.
+// tmp: N floats of LDS scratch.
+__device__ __forceinline__ void ln_relu_drop_bwd(const float* d_in, float* g, float* tmp, int N,
+                                                 const float* __restrict__ pre_g, const float* __restrict__ stats_g,
+                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                 float* dln_g, float* dpre_g, int b, float drop_p,
+                                                 unsigned long long seed) {
   const float mean = stats_g[2 * b], rstd = stats_g[2 * b + 1];
   const float ks = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
-  float s1 = 0.f, s2 = 0.f;
-  for (int n = threadIdx.x; n < N; n += HT) {
+  float xh_keep[1];   // N <= 512 < HT: one element per thread
+  const int n = threadIdx.x;
+  xh_keep[0] = 0.f;
+  if (n < N) {
     float d = d_in[n];
     if (drop_p > 0.f) d = hash_uniform(seed, (unsigned long long)b * N + n) >= drop_p ? d * ks : 0.f;
     const float xh = (pre_g[(long)b * N + n] - mean) * rstd;
@@ -163,14 +192,15 @@ __device__ __forceinline__ void ln_relu_drop_bwd(const float* d_in, float* g, in
     dln_g[(long)b * N + n] = d;
     const float dg = d * gamma[n];
     g[n] = dg;
-    s1 += dg;
-    s2 = fmaf(dg, xh, s2);
+    tmp[n] = dg * xh;
+    xh_keep[0] = xh;
   }
-  s1 = block_sum(s1, red) / (float)N;
-  s2 = block_sum(s2, red) / (float)N;
-  for (int n = threadIdx.x; n < N; n += HT) {
-    const float xh = (pre_g[(long)b * N + n] - mean) * rstd;
-    const float v = rstd * (g[n] - s1 - xh * s2);
+  __syncthreads();
+  const float s1 = wave_row_sum(g, N) / (float)N;
+  const float s2 = wave_row_sum(tmp, N) / (float)N;
+  __syncthreads();   // every wave has read g / tmp
+  if (n < N) {
+    const float v = rstd * (g[n] - s1 - xh_keep[0] * s2);
     g[n] = v;
     dpre_g[(long)b * N + n] = v;
   }
@@ -182,7 +212,6 @@ __global__ __launch_bounds__(HT) void head_both_fwd_kernel(const HeadPtrs h, con
   __shared__ __attribute__((aligned(16))) float s_pre[1024];   // linear outputs of the current layer
   __shared__ __attribute__((aligned(16))) float s_P[1024];     // projected audio | text
   __shared__ __attribute__((aligned(16))) float s_x[512];      // fused / hidden vectors
-  __shared__ float red[32];
   const int b = blockIdx.x, t = threadIdx.x;
   const int A = d.A, T = d.T, Hd = d.Hd;
 
@@ -192,7 +221,7 @@ __global__ __launch_bounds__(HT) void head_both_fwd_kernel(const HeadPtrs h, con
   __syncthreads();
   {
     float mean, rstd;
-    row_stats(s_pre, A, red, mean, rstd);
+    row_stats(s_pre, A, mean, rstd);
     if (t == 0) { mf(h, S_AN_STATS)[2 * b] = mean; mf(h, S_AN_STATS)[2 * b + 1] = rstd; }
     const float sc = cf(h, S_A_SCALE)[0] * (h.p[S_KEEP_A] ? cf(h, S_KEEP_A)[0] : 1.f);
     for (int n = t; n < A; n += HT) {
@@ -200,7 +229,7 @@ __global__ __launch_bounds__(HT) void head_both_fwd_kernel(const HeadPtrs h, con
       s_in[n] = v;
       mf(h, S_AN)[(long)b * A + n] = v;
     }
-    row_stats(s_pre + 512, T, red, mean, rstd);
+    row_stats(s_pre + 512, T, mean, rstd);
     if (t == 0) { mf(h, S_TN_STATS)[2 * b] = mean; mf(h, S_TN_STATS)[2 * b + 1] = rstd; }
     const float st = cf(h, S_T_SCALE)[0] * (h.p[S_KEEP_T] ? cf(h, S_KEEP_T)[0] : 1.f);
     for (int n = t; n < T; n += HT) {
@@ -217,9 +246,9 @@ __global__ __launch_bounds__(HT) void head_both_fwd_kernel(const HeadPtrs h, con
   __syncthreads();
   float* Pg = mf(h, S_P) + (long)b * 2 * Hd;
   ln_relu_drop(s_pre, Hd, cf(h, S_GPA), cf(h, S_BEPA), s_P, Pg, mf(h, S_PA_PRE), mf(h, S_PA_STATS), b, d.drop_p,
-               d.seed + 1, red);
+               d.seed + 1);
   ln_relu_drop(s_pre + 512, Hd, cf(h, S_GPT), cf(h, S_BEPT), s_P + Hd, Pg + Hd, mf(h, S_PT_PRE), mf(h, S_PT_STATS), b,
-               d.drop_p, d.seed + 2, red);
+               d.drop_p, d.seed + 2);
 
   // attention over the two modalities and the weighted sum
   matvec(cf(h, S_WATT), cf(h, S_BATT), s_P, s_pre, 2 * Hd, 2);
@@ -245,11 +274,11 @@ __global__ __launch_bounds__(HT) void head_both_fwd_kernel(const HeadPtrs h, con
   matvec(cf(h, S_W0), cf(h, S_B0), s_x, s_pre, Hd, d.N0);
   __syncthreads();
   ln_relu_drop(s_pre, d.N0, cf(h, S_G0), cf(h, S_BE0), s_x, mf(h, S_H1) + (long)b * d.N0, mf(h, S_C0_PRE),
-               mf(h, S_C0_STATS), b, d.drop_p, d.seed + 3, red);
+               mf(h, S_C0_STATS), b, d.drop_p, d.seed + 3);
   matvec(cf(h, S_W1), cf(h, S_B1), s_x, s_pre, d.N0, d.N1);
   __syncthreads();
   ln_relu_drop(s_pre, d.N1, cf(h, S_G1), cf(h, S_BE1), s_x, mf(h, S_H2) + (long)b * d.N1, mf(h, S_C1_PRE),
-               mf(h, S_C1_STATS), b, 0.5f * d.drop_p, d.seed + 4, red);
+               mf(h, S_C1_STATS), b, 0.5f * d.drop_p, d.seed + 4);
   matvec(cf(h, S_W2), cf(h, S_B2), s_x, s_pre, d.N1, d.C);
   __syncthreads();
   for (int n = t; n < d.C; n += HT) mf(h, S_LOGITS)[(long)b * d.C + n] = s_pre[n];
@@ -260,7 +289,6 @@ __global__ __launch_bounds__(HT) void head_both_bwd_kernel(const HeadPtrs h, con
   __shared__ float s_g[1024];     // gradient w.r.t. the current layer's linear output
   __shared__ float s_dP[1024];    // gradient w.r.t. the projected audio | text
   __shared__ float part[HT];
-  __shared__ float red[32];
   const int b = blockIdx.x, t = threadIdx.x;
   const int A = d.A, T = d.T, Hd = d.Hd, N0 = d.N0, N1 = d.N1, C = d.C;
 
@@ -268,27 +296,26 @@ __global__ __launch_bounds__(HT) void head_both_bwd_kernel(const HeadPtrs h, con
   for (int n = t; n < C; n += HT) s_g[n] = cf(h, S_DLOGITS)[(long)b * C + n];
   __syncthreads();
   matvec_t(cf(h, S_W2), s_g, s_d, part, N1, C, false);
-  ln_relu_drop_bwd(s_d, s_g, N1, cf(h, S_C1_PRE), cf(h, S_C1_STATS), cf(h, S_G1), cf(h, S_BE1), mf(h, S_C1_DLN),
-                   mf(h, S_C1_DPRE), b, 0.5f * d.drop_p, d.seed + 4, red);
+  ln_relu_drop_bwd(s_d, s_g, part, N1, cf(h, S_C1_PRE), cf(h, S_C1_STATS), cf(h, S_G1), cf(h, S_BE1),
+                   mf(h, S_C1_DLN), mf(h, S_C1_DPRE), b, 0.5f * d.drop_p, d.seed + 4);
   matvec_t(cf(h, S_W1), s_g, s_d, part, N0, N1, false);
-  ln_relu_drop_bwd(s_d, s_g, N0, cf(h, S_C0_PRE), cf(h, S_C0_STATS), cf(h, S_G0), cf(h, S_BE0), mf(h, S_C0_DLN),
-                   mf(h, S_C0_DPRE), b, d.drop_p, d.seed + 3, red);
+  ln_relu_drop_bwd(s_d, s_g, part, N0, cf(h, S_C0_PRE), cf(h, S_C0_STATS), cf(h, S_G0), cf(h, S_BE0),
+                   mf(h, S_C0_DLN), mf(h, S_C0_DPRE), b, d.drop_p, d.seed + 3);
   matvec_t(cf(h, S_W0), s_g, s_d, part, Hd, N0, false);      // s_d = d fused
 
   // weighted sum and the softmax over the two attention scores
   {
     const float* Pg = cf(h, S_P) + (long)b * 2 * Hd;
     const float w0 = cf(h, S_WTS)[2 * b], w1 = cf(h, S_WTS)[2 * b + 1];
-    float d0 = 0.f, d1 = 0.f;
     for (int n = t; n < Hd; n += HT) {
       const float df = s_d[n];
-      d0 = fmaf(df, Pg[n], d0);
-      d1 = fmaf(df, Pg[Hd + n], d1);
+      part[n] = df * Pg[n];
+      part[512 + n] = df * Pg[Hd + n];
       s_dP[n] = df * w0;
       s_dP[Hd + n] = df * w1;
     }
-    d0 = block_sum(d0, red);
-    d1 = block_sum(d1, red);
+    __syncthreads();
+    const float d0 = wave_row_sum(part, Hd), d1 = wave_row_sum(part + 512, Hd);
     const float dot = w0 * d0 + w1 * d1;
     const float g0 = w0 * (d0 - dot), g1 = w1 * (d1 - dot);
     if (t == 0) {
@@ -300,11 +327,11 @@ __global__ __launch_bounds__(HT) void head_both_bwd_kernel(const HeadPtrs h, con
   matvec_t(cf(h, S_WATT), s_g, s_dP, part, 2 * Hd, 2, true);
 
   // projectors, then the feature normaliser
-  ln_relu_drop_bwd(s_dP, s_g, Hd, cf(h, S_PA_PRE), cf(h, S_PA_STATS), cf(h, S_GPA), cf(h, S_BEPA), mf(h, S_PA_DLN),
-                   mf(h, S_PA_DPRE), b, d.drop_p, d.seed + 1, red);
+  ln_relu_drop_bwd(s_dP, s_g, part, Hd, cf(h, S_PA_PRE), cf(h, S_PA_STATS), cf(h, S_GPA), cf(h, S_BEPA),
+                   mf(h, S_PA_DLN), mf(h, S_PA_DPRE), b, d.drop_p, d.seed + 1);
   matvec_t(cf(h, S_WPA), s_g, s_d, part, A, Hd, false);       // s_d[0..A) = d an
-  ln_relu_drop_bwd(s_dP + Hd, s_g, Hd, cf(h, S_PT_PRE), cf(h, S_PT_STATS), cf(h, S_GPT), cf(h, S_BEPT),
-                   mf(h, S_PT_DLN), mf(h, S_PT_DPRE), b, d.drop_p, d.seed + 2, red);
+  ln_relu_drop_bwd(s_dP + Hd, s_g, part, Hd, cf(h, S_PT_PRE), cf(h, S_PT_STATS), cf(h, S_GPT), cf(h, S_BEPT),
+                   mf(h, S_PT_DLN), mf(h, S_PT_DPRE), b, d.drop_p, d.seed + 2);
   matvec_t(cf(h, S_WPT), s_g, s_d + 512, part, T, Hd, false);  // s_d[512..512+T) = d tn
 
 #pragma unroll 1
@@ -321,21 +348,21 @@ __global__ __launch_bounds__(HT) void head_both_bwd_kernel(const HeadPtrs h, con
     const float mean = stats[2 * b], rstd = stats[2 * b + 1];
     const float kp = keep ? keep[0] : 1.f;
     const float sc = cf(h, which ? S_T_SCALE : S_A_SCALE)[0] * kp;
-    float s1 = 0.f, s2 = 0.f, ds = 0.f;
     for (int n = t; n < N; n += HT) {
       const float dv = dy[n];
       const float xh = (x[n] - mean) * rstd;
       const float dl = dv * sc;
       dln[n] = dl;
       s_g[n] = dl;
-      ds = fmaf(dv * kp, fmaf(xh, gam[n], bet[n]), ds);
+      s_dP[n] = dv * kp * fmaf(xh, gam[n], bet[n]);
       const float dg = dl * gam[n];
-      s1 += dg;
-      s2 = fmaf(dg, xh, s2);
+      part[n] = dg;
+      part[512 + n] = dg * xh;
     }
-    s1 = block_sum(s1, red) / (float)N;
-    s2 = block_sum(s2, red) / (float)N;
-    ds = block_sum(ds, red);
+    __syncthreads();
+    const float s1 = wave_row_sum(part, N) / (float)N;
+    const float s2 = wave_row_sum(part + 512, N) / (float)N;
+    const float ds = wave_row_sum(s_dP, N);
     if (t == 0) mf(h, which ? S_T_DSPART : S_A_DSPART)[b] = ds;
     for (int n = t; n < N; n += HT) {
       const float xh = (x[n] - mean) * rstd;
