@@ -50,6 +50,15 @@ MMSA_API int mmsa_logmel_tables_host(float* window_host, float* tw512_host, floa
 MMSA_API int mmsa_logmel_fwd(const float* wave, long wave_stride, int n_valid, int n_target, int batch,
                              const float* window, const float* tw512, const float* tw1024, const float* melfb,
                              const int* melrange, float top_db, float* out, void* stream);
+/* Resampling ahead of the mel stage: torchaudio.transforms.Resample's sinc interpolation (Hann window,
+ * lowpass_filter_width 6, rolloff 0.99) as applied at preprocess.py:131-134, fused with the mono mix (:127-129) and
+ * the pad / trim to n_out samples (:151-156).  mmsa_resample_filters_host builds the filter bank kernT[K][new] on the
+ * host (null kernT: size query); mmsa_resample_fwd maps pcm [batch][channels][T] to out [batch][n_out]. */
+MMSA_API int mmsa_resample_filters_host(int orig_freq, int new_freq, int lowpass_filter_width, double rolloff,
+                                        float* kernT, int* orig_out, int* new_out, int* width_out, int* K_out);
+MMSA_API int mmsa_resample_fwd(const float* pcm, int channels, long T, long stride_b, const float* kernT, int orig,
+                               int nw, int width, int K, float* out, int n_out, int batch, void* stream);
+
 
 /* ---- convolutions as implicit GEMM on fp32 MFMA: multimodal_model.py:48-59,64-68 (ResidualBlock convs and 1x1
  *      shortcut), :152-155,188 (text Conv1d); backward = autograd of the same (multimodal_train.py:192). ------ */

@@ -190,3 +190,98 @@ MMSA_EXPORT int mmsa_logmel_fwd(const float* wave, long wave_stride, int n_valid
                      n_elem, top_db);
   return mmsa_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ resampling
+// Band-limited sinc interpolation with a Hann window, the algorithm of torchaudio.transforms.Resample (defaults
+// lowpass_filter_width 6, rolloff 0.99) that `CNN implementation/preprocess.py:131-134` applies per utterance, fused
+// with the mono mix (`:127-129`) and the pad / trim to the model's input length (`:151-156`).
+// With orig / new reduced by their gcd, output sample i*new + p is the dot product of filter p ([K] taps) with the
+// zero-padded input window starting at sample i*orig - width.
+namespace {
+
+constexpr int RS_FRAMES = 4;   // input strides (of `orig` samples) per workgroup
+
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ pcm, int channels, long T,
+                                                       long stride_b, const float* __restrict__ kernT, int orig, int nw,
+                                                       int width, int K, long n_res, float* __restrict__ out, int n_out) {
+  extern __shared__ float win[];   // mono-mixed, zero-padded input window of RS_FRAMES strides plus the filter tail
+  const int b = blockIdx.y;
+  const long i0 = (long)blockIdx.x * RS_FRAMES;
+  const int nwin = RS_FRAMES * orig + K;
+  const float* src = pcm + (long)b * stride_b;
+  for (int i = threadIdx.x; i < nwin; i += 256) {
+    const long n = i0 * orig + i - width;
+    float v = 0.f;
+    if (n >= 0 && n < T) {
+      for (int c = 0; c < channels; ++c) v += src[(long)c * T + n];
+      if (channels > 1) v = v / (float)channels;
+    }
+    win[i] = v;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < RS_FRAMES * nw; o += 256) {
+    const int fr = o / nw, p = o - fr * nw;
+    const long j = (i0 + fr) * nw + p;        // output sample
+    if (j >= n_out) continue;
+    float acc = 0.f;
+    if (j < n_res) {
+      const float* x = win + fr * orig;
+      for (int k = 0; k < K; ++k) acc = fmaf(kernT[(long)k * nw + p], x[k], acc);
+    }
+    out[(long)b * n_out + j] = acc;           // samples past the resampled length are the zero padding
+  }
+}
+
+long rs_gcd(long a, long b) { while (b) { const long t = a % b; a = b; b = t; } return a; }
+
+}  // namespace
+
+// Filter bank of the resampler, built on the host in double precision (torchaudio's construction) and stored
+// transposed, kernT[K][new], so that consecutive output phases read consecutive floats.  Returns through the out
+// parameters the reduced rates, the one-sided filter width and the tap count K = 2*width + orig; kernT may be null
+// to query the sizes first.
+MMSA_EXPORT int mmsa_resample_filters_host(int orig_freq, int new_freq, int lowpass_filter_width, double rolloff,
+                                           float* kernT, int* orig_out, int* new_out, int* width_out, int* K_out) {
+  MMSA_REQUIRE(orig_freq > 0 && new_freq > 0 && lowpass_filter_width > 0 && rolloff > 0.0 && rolloff <= 1.0);
+  MMSA_REQUIRE(orig_out && new_out && width_out && K_out);
+  const long g = rs_gcd(orig_freq, new_freq);
+  const int orig = (int)(orig_freq / g), nw = (int)(new_freq / g);
+  const double base = (double)(orig < nw ? orig : nw) * rolloff;
+  const int width = (int)ceil((double)lowpass_filter_width * orig / base);
+  const int K = 2 * width + orig;
+  *orig_out = orig; *new_out = nw; *width_out = width; *K_out = K;
+  if (!kernT) return MMSA_OK;
+  const double pi = 3.14159265358979323846, lpw = (double)lowpass_filter_width;
+  const double scale = base / orig;
+  for (int p = 0; p < nw; ++p)
+    for (int k = 0; k < K; ++k) {
+      double t = (-(double)p / nw + (double)(k - width) / orig) * base;
+      if (t < -lpw) t = -lpw;
+      if (t > lpw) t = lpw;
+      const double c = cos(t * pi / lpw / 2.0);
+      const double window = c * c;
+      t *= pi;
+      const double s = t == 0.0 ? 1.0 : sin(t) / t;
+      kernT[(long)k * nw + p] = (float)(s * window * scale);
+    }
+  return MMSA_OK;
+}
+
+// pcm: [batch][channels][T] (utterance stride `stride_b` floats) at the original rate -> out [batch][n_out] at the
+// new rate: mono mix, resample (resampled length ceil(new*T/orig)), zero pad or trim to n_out.
+MMSA_EXPORT int mmsa_resample_fwd(const float* pcm, int channels, long T, long stride_b, const float* kernT, int orig,
+                                  int nw, int width, int K, float* out, int n_out, int batch, void* stream) {
+  MMSA_REQUIRE(pcm && kernT && out && channels > 0 && T > 0 && batch > 0 && batch <= 65535 && n_out > 0);
+  MMSA_REQUIRE(orig > 0 && nw > 0 && width > 0 && K == 2 * width + orig && stride_b >= (long)channels * T);
+  const size_t sh = (size_t)(RS_FRAMES * orig + K) * sizeof(float);
+  if (sh > 150 * 1024) return MMSA_ERR_LIMIT;
+  if (sh > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(resample_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) != hipSuccess)
+    return MMSA_ERR_LAUNCH;
+  const long n_res = ((long)nw * T + orig - 1) / orig;
+  const int frames = mmsa_cdiv(n_out, nw);
+  dim3 grid(mmsa_cdiv(frames, RS_FRAMES), batch);
+  hipLaunchKernelGGL(resample_kernel, grid, dim3(256), sh, mmsa_stream(stream), pcm, channels, T, stride_b, kernT, orig,
+                     nw, width, K, n_res, out, n_out);
+  return mmsa_launch_status();
+}

@@ -5,8 +5,9 @@
 batched HIP call: :class:`LogMelFrontEnd` maps ``[B, n]`` waveforms to ``[B, 1, 64, 130]``.
 :class:`AudioTransform` keeps the reference's per-utterance call signature on top of it.
 
-Not covered here (they sit before the kernel boundary and depend on packages absent from this image):
-resampling from other sample rates and spectral-gating noise reduction (`preprocess.py:131-148`).
+Input at another sample rate goes through :class:`Resampler` first (`preprocess.py:131-134`: torchaudio's sinc
+resampler, one HIP launch per batch, fused with the mono mix and the pad / trim).  Not covered: the spectral-gating
+noise reduction of `preprocess.py:142-148` (the `noisereduce` package is absent from this image).
 """
 from __future__ import annotations
 
@@ -98,6 +99,35 @@ class LogMelFrontEnd:
         return ops.logmel(wave, self.tables, out, TARGET_LENGTH, TOP_DB)
 
 
+class Resampler:
+    """``rs(pcm[B, C, T]) -> [B, n_out]`` at 22 050 Hz on ``device``: mono mix, band-limited sinc resampling with
+    torchaudio's defaults (Hann window, lowpass_filter_width 6, rolloff 0.99) and zero pad / trim to ``n_out`` samples
+    (default: the model's 66 150; ``n_out=None`` keeps the full resampled length ``ceil(22050 * T / sr)``)."""
+
+    def __init__(self, orig_freq: int, new_freq: int = SAMPLE_RATE, device="cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MmsaError("Resampler runs on an MI355X only; there is no CPU path")
+        self.orig_freq, self.new_freq = int(orig_freq), int(new_freq)
+        self.filters = ops.resample_filters(self.orig_freq, self.new_freq, self.device)
+
+    def resampled_length(self, T: int) -> int:
+        f = self.filters
+        return -(-f["new"] * int(T) // f["orig"])
+
+    def __call__(self, pcm: torch.Tensor, n_out=TARGET_LENGTH, out: torch.Tensor = None) -> torch.Tensor:
+        if pcm.dim() == 1:
+            pcm = pcm[None, None]
+        elif pcm.dim() == 2:
+            pcm = pcm.unsqueeze(0)
+        pcm = pcm.to(device=self.device, dtype=torch.float32).contiguous()
+        if n_out is None:
+            n_out = self.resampled_length(pcm.shape[2])
+        if out is None:
+            out = torch.empty((pcm.shape[0], n_out), dtype=torch.float32, device=self.device)
+        return ops.resample(pcm, self.filters, out)
+
+
 class AudioTransform:
     """Per-utterance interface of the reference (``transform(audio[C, T], sr) -> [1, 64, 130]`` CPU tensor).
 
@@ -112,10 +142,12 @@ class AudioTransform:
         self.device = device
         self.waveform_only = waveform_only
         self._fe = None
+        self._rs = {}
 
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_fe"] = None            # device tables are rebuilt lazily in the receiving process
+        d["_rs"] = {}
         return d
 
     # -- augmentations (host side, training only) ------------------------------------------------
@@ -161,15 +193,17 @@ class AudioTransform:
         return spec
 
     def prepare_waveform(self, audio: torch.Tensor, sr: int = SAMPLE_RATE) -> torch.Tensor:
-        """Everything before the mel stage that this build covers: mono mix, augmentation, pad/trim."""
+        """Everything before the mel stage that this build covers: mono mix, resampling, augmentation, pad/trim."""
         if audio.dim() == 1:
             audio = audio.unsqueeze(0)
-        if audio.shape[0] > 1:
-            audio = audio.mean(dim=0, keepdim=True)
         if sr != SAMPLE_RATE:
-            raise NotImplementedError(
-                f"resampling {sr} Hz -> {SAMPLE_RATE} Hz is outside this build's kernel boundary "
-                "(the reference uses torchaudio.transforms.Resample, absent here); resample upstream")
+            # preprocess.py:127-134: mono mix and resampling in one HIP launch (needs the process that owns the GPU)
+            if sr not in self._rs:
+                self._rs[sr] = Resampler(sr, SAMPLE_RATE, self.device)
+            n_out = None if self.augment else TARGET_LENGTH   # augmentations see the full resampled length
+            audio = self._rs[sr](audio, n_out=n_out).cpu()
+        elif audio.shape[0] > 1:
+            audio = audio.mean(dim=0, keepdim=True)
         if self.augment:
             audio = self.time_shift(audio)
             audio = self.add_noise(audio)

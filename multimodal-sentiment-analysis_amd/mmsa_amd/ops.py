@@ -87,6 +87,27 @@ def logmel(wave: torch.Tensor, tables, out: torch.Tensor, n_target: int = 66150,
     return out
 
 
+def resample_filters(orig_freq: int, new_freq: int, device, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """Filter bank of the sinc resampler as a dict for :func:`resample` (built on the host by the library)."""
+    geo = (ctypes.c_int * 4)()
+    ptrs = [ctypes.cast(ctypes.byref(geo, 4 * i), ctypes.c_void_p) for i in range(4)]
+    _lib.call("mmsa_resample_filters_host", orig_freq, new_freq, lowpass_filter_width, rolloff, None, *ptrs)
+    orig, new, width, K = (int(v) for v in geo)
+    host = torch.empty((K, new), dtype=F32)
+    _lib.call("mmsa_resample_filters_host", orig_freq, new_freq, lowpass_filter_width, rolloff, host.data_ptr(), *ptrs)
+    return {"kernT": host.to(device), "orig": orig, "new": new, "width": width, "K": K}
+
+
+def resample(pcm: torch.Tensor, filt, out: torch.Tensor):
+    """pcm [B, C, T] at the original rate -> out [B, n_out]: mono mix, sinc resampling, zero pad / trim to n_out."""
+    if pcm.dim() != 3 or out.dim() != 2 or out.shape[0] != pcm.shape[0]:
+        raise ValueError("pcm must be [B, C, T] and out [B, n_out]")
+    B, C, T = pcm.shape
+    _lib.call("mmsa_resample_fwd", _chk(pcm, name="pcm"), C, T, C * T, _chk(filt["kernT"]), filt["orig"], filt["new"],
+              filt["width"], filt["K"], _chk(out, name="out"), out.shape[1], B, _stream())
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- convolution
 def pack_weights(w: torch.Tensor, fwd: Optional[torch.Tensor], dgrad: Optional[torch.Tensor]):
     cout, cin = w.shape[0], w.shape[1]

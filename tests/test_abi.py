@@ -43,6 +43,47 @@ def test_host_table_helper_and_geometry_queries():
         _lib.query("mmsa_resblock_bwd_scratch_floats", 32, 32, 65, 48)      # channels must be 64/128/256
 
 
+def test_resample_filter_bank_matches_oracle_and_has_unit_dc_gain():
+    """Host-built filter bank of the resampler == the oracle's float64 construction, for the rates the datasets use."""
+    from mmsa_amd import _lib
+    from oracle import resample_ref
+    for sr, want in ((16000, (320, 441, 7, 334)), (44100, (2, 1, 13, 28)), (48000, (320, 147, 14, 348)),
+                     (8000, (160, 441, 7, 174))):
+        geo = (ctypes.c_int * 4)()
+        ptrs = [ctypes.cast(ctypes.byref(geo, 4 * i), ctypes.c_void_p) for i in range(4)]
+        _lib.call("mmsa_resample_filters_host", sr, 22050, 6, 0.99, None, *ptrs)
+        orig, new, width, K = (int(v) for v in geo)
+        assert (orig, new, width, K) == want
+        kern_t = np.zeros((K, new), np.float32)
+        _lib.call("mmsa_resample_filters_host", sr, 22050, 6, 0.99, kern_t.ctypes.data_as(ctypes.c_void_p), *ptrs)
+        filt, w, o, n = resample_ref.sinc_filters(sr, 22050)
+        assert (o, n, w) == (orig, new, width) and filt.shape == (new, K)
+        np.testing.assert_allclose(kern_t.T, filt, rtol=0, atol=2e-7)
+        # every output phase passes DC at the gain of a windowed sinc cut just below Nyquist
+        assert np.abs(filt.sum(1) - 1.0).max() < 2e-3
+    lib = _lib.load()
+    assert lib.mmsa_resample_fwd(None, 1, 100, 100, None, 320, 441, 7, 334, None, 66150, 1, None) == -1
+
+
+def test_resample_oracle_reconstructs_a_tone():
+    """The restated sinc resampler maps a 440 Hz tone at 16 kHz onto the same tone at 22.05 kHz (|err| < 1e-3 away
+    from the edges), yields ceil(new * T / orig) samples, and `prepare` pads / trims to 66 150."""
+    from oracle import resample_ref
+    t = np.arange(16000) / 16000.0
+    x = np.sin(2 * np.pi * 440 * t).astype(np.float32)
+    y = resample_ref.resample(x, 16000, 22050)
+    assert y.shape == (22050,)
+    t2 = np.arange(22050) / 22050.0
+    assert np.abs(y[200:-200] - np.sin(2 * np.pi * 440 * t2)[200:-200]).max() < 1e-3
+    assert resample_ref.resample(x[:1001], 16000, 22050).shape == (1380,)      # ceil(441 * 1001 / 320)
+    stereo = np.stack([x, -x * 0.5])
+    out = resample_ref.prepare(stereo, 16000)
+    assert out.shape == (66150,) and np.all(out[22050:] == 0)
+    np.testing.assert_allclose(out[:22050], 0.25 * y, atol=1e-6)
+    long = resample_ref.prepare(np.tile(x, 4)[None], 16000)
+    assert long.shape == (66150,) and np.abs(long[-100:]).max() > 0.1
+
+
 def test_bad_arguments_are_rejected_before_any_launch():
     from mmsa_amd import _lib
     lib = _lib.load()

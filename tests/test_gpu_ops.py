@@ -74,6 +74,41 @@ def test_logmel_edge_cases():
     check(got, ref, 1e-4)
 
 
+@pytest.mark.parametrize("sr,C,T,B", [(16000, 1, 48000, 3), (16000, 2, 20001, 2), (8000, 1, 30000, 2),
+                                      (44100, 2, 150000, 2), (48000, 1, 100000, 1)])
+def test_resample_matches_oracle(sr, C, T, B):
+    """Mono mix + sinc resampling + pad/trim vs the oracle accumulated in float64: |err| < 2e-6 * max|y| (fp32
+    accumulation over <= 348 taps); the zero padding past the resampled length is exact."""
+    from mmsa_amd.frontend import Resampler
+    from oracle import resample_ref
+    g = torch.Generator().manual_seed(sr + T)
+    pcm = torch.randn(B, C, T, generator=g) * 0.2
+    rs = Resampler(sr, 22050, DEV)
+    got = rs(pcm.to(DEV)).cpu()
+    assert got.shape == (B, 66150)
+    ref = np.stack([resample_ref.prepare(pcm[b].numpy(), sr, dtype=np.float64) for b in range(B)])
+    check(got, torch.from_numpy(ref), 2e-6)
+    n_res = rs.resampled_length(T)
+    if n_res < 66150:
+        assert torch.equal(got[:, n_res:], torch.zeros(B, 66150 - n_res))
+    full = rs(pcm.to(DEV), n_out=None).cpu()
+    assert full.shape == (B, n_res)
+    n = min(n_res, 66150)
+    assert torch.equal(full[:, :n], got[:, :n])
+
+
+def test_audio_transform_accepts_16k_input():
+    """The reference's per-utterance call with sr != 22050 (preprocess.py:125-134): resample, then the mel stage."""
+    from mmsa_amd.frontend import AudioTransform
+    from oracle import frontend_ref, resample_ref
+    g = torch.Generator().manual_seed(11)
+    audio = torch.randn(2, 40000, generator=g) * 0.1
+    spec = AudioTransform(augment=False, device=DEV)(audio, 16000)
+    assert spec.shape == (1, 64, 130) and not spec.is_cuda
+    wave = resample_ref.prepare(audio.numpy(), 16000, dtype=np.float64)
+    check(spec, torch.from_numpy(frontend_ref.logmel_f64(wave[None]))[0], 1e-4)
+
+
 # ------------------------------------------------------------------------------------------------ gather
 def test_embedding_gather_bit_exact():
     ops = _ops()
