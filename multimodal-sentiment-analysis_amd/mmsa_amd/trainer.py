@@ -196,3 +196,35 @@ class TrainStep:
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
                  "differentiable": False, "fused": None, "params": list(range(len(ms)))}
         return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """Inverse of :meth:`state_dict`: accepts what ``torch.optim.AdamW.state_dict()`` of the reference's optimiser
+        (same parameter order, one group) or this class wrote."""
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.arena.params):
+            raise ValueError("optimizer state does not match this model: expected one group of "
+                             f"{len(self.arena.params)} parameters")
+        grp = groups[0]
+        self.wd, self.eps, self.betas = grp["weight_decay"], grp["eps"], tuple(grp["betas"])
+        self.set_lr(grp["lr"])
+        ms, vs = self.arena.views_of(self.m), self.arena.views_of(self.v)
+        state = sd["state"]
+        step = 0.0
+        self.m.zero_()
+        self.v.zero_()
+        for i, key in enumerate(grp["params"]):
+            st = state.get(key)
+            if st is None:
+                continue
+            ms[i].copy_(st["exp_avg"].reshape(ms[i].shape))
+            vs[i].copy_(st["exp_avg_sq"].reshape(vs[i].shape))
+            step = max(step, float(st["step"]))
+        self.state[0] = step
+
+    def set_lr(self, lr: float):
+        """Learning-rate change from a scheduler (multimodal_train.py:314-320).  Scalars are baked into a captured
+        launch sequence, so graph mode re-captures on the next step."""
+        if float(lr) != self.lr or self._graph is None:
+            self.lr = float(lr)
+            self._graph = None
+
