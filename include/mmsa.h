@@ -46,10 +46,18 @@ extern "C" {
 /* host helper: periodic Hann window [1024], FFT twiddles tw512 [256][2], tw1024 [513][2] (cos, -sin), in double */
 MMSA_API int mmsa_logmel_tables_host(float* window_host, float* tw512_host, float* tw1024_host);
 /* wave: [batch] rows of n_valid samples (row stride wave_stride floats) -> out [batch][1][64][1 + n_target/512].
- * melfb [513][64] and melrange [64][2] (first bin, one past last bin with weight) describe the filterbank. */
+ * melfb [513][64] and melrange [64][2] (first bin, one past last bin with weight) describe the filterbank.
+ * specmask: null, or [batch][4] ints {first mel row, rows, first frame, frames}: the training-time frequency / time
+ * masks of preprocess.py:92-109, zero-filled after the dB floor and before normalisation (:162-165). */
 MMSA_API int mmsa_logmel_fwd(const float* wave, long wave_stride, int n_valid, int n_target, int batch,
                              const float* window, const float* tw512, const float* tw1024, const float* melfb,
-                             const int* melrange, float top_db, float* out, void* stream);
+                             const int* melrange, float top_db, const int* specmask, float* out, void* stream);
+/* Training-time waveform augmentations of preprocess.py:56-90,137-140 (time shift, Gaussian noise, resample-by-index
+ * "pitch shift") for a batch, fused with the pad / trim to n_target (:151-156).  params: [batch][4] doubles drawn on
+ * the host {shift mode 0 none / 1 right / 2 left, shift in samples, noise on, index step or 0}.  The noise comes from
+ * a counter-based generator keyed by (seed, utterance, sample), not from torch's stream. */
+MMSA_API int mmsa_augment_wave(const float* in, long in_stride, int n_in, const double* params, float noise_factor,
+                               unsigned long long seed, float* out, int n_target, int batch, void* stream);
 /* Resampling ahead of the mel stage: torchaudio.transforms.Resample's sinc interpolation (Hann window,
  * lowpass_filter_width 6, rolloff 0.99) as applied at preprocess.py:131-134, fused with the mono mix (:127-129) and
  * the pad / trim to n_out samples (:151-156).  mmsa_resample_filters_host builds the filter bank kernT[K][new] on the

@@ -115,7 +115,10 @@ __global__ __launch_bounds__(256) void logmel_db_kernel(
   }
 }
 
-__global__ __launch_bounds__(1024) void logmel_norm_kernel(float* __restrict__ io, int n_elem, float top_db) {
+// specmask (optional): per utterance {first mel row, rows, first frame, frames} zero-filled after the dB floor and
+// before the statistics (preprocess.py:92-109,162-165); a zero count disables that mask.
+__global__ __launch_bounds__(1024) void logmel_norm_kernel(float* __restrict__ io, int n_elem, int n_frames,
+                                                           float top_db, const int* __restrict__ specmask) {
   extern __shared__ float vals[];
   __shared__ float redf[16];
   __shared__ double redd[16];
@@ -129,9 +132,16 @@ __global__ __launch_bounds__(1024) void logmel_norm_kernel(float* __restrict__ i
   }
   mx = block_max(mx, redf);
   const float floor_v = mx - top_db;
+  int mf0 = 0, mfn = 0, mt0 = 0, mtn = 0;
+  if (specmask) {
+    const int* mk = specmask + 4 * blockIdx.x;
+    mf0 = mk[0]; mfn = mk[1]; mt0 = mk[2]; mtn = mk[3];
+  }
   double s = 0.0;
   for (int i = t; i < n_elem; i += 1024) {
-    const float v = fmaxf(vals[i], floor_v);
+    float v = fmaxf(vals[i], floor_v);
+    const int row = i / n_frames, col = i - row * n_frames;
+    if ((unsigned)(row - mf0) < (unsigned)mfn || (unsigned)(col - mt0) < (unsigned)mtn) v = 0.f;
     vals[i] = v;
     s += (double)v;
   }
@@ -174,9 +184,10 @@ MMSA_EXPORT int mmsa_logmel_tables_host(float* window /*[1024]*/, float* tw512 /
 
 // wave: [batch] rows of `n_valid` samples, row stride `wave_stride` floats.  Samples beyond n_valid are
 // zeros up to n_target (pad) and samples beyond n_target are ignored (trim).  out: [batch][1][64][n_frames].
+// specmask: null, or [batch][4] ints {first mel row, rows, first frame, frames} of the training-time spectral masks.
 MMSA_EXPORT int mmsa_logmel_fwd(const float* wave, long wave_stride, int n_valid, int n_target, int batch,
                                 const float* window, const float* tw512, const float* tw1024, const float* melfb,
-                                const int* melrange, float top_db, float* out, void* stream) {
+                                const int* melrange, float top_db, const int* specmask, float* out, void* stream) {
   MMSA_REQUIRE(wave && window && tw512 && tw1024 && melfb && melrange && out);
   MMSA_REQUIRE(batch > 0 && n_target >= NFFT && n_valid >= 0 && wave_stride >= 0);
   if (n_valid > n_target) n_valid = n_target;
@@ -187,7 +198,7 @@ MMSA_EXPORT int mmsa_logmel_fwd(const float* wave, long wave_stride, int n_valid
   hipLaunchKernelGGL(logmel_db_kernel, grid, dim3(256), 0, mmsa_stream(stream), wave, wave_stride, n_valid, n_target,
                      n_frames, window, tw512, tw1024, melfb, melrange, out);
   hipLaunchKernelGGL(logmel_norm_kernel, dim3(batch), dim3(1024), n_elem * sizeof(float), mmsa_stream(stream), out,
-                     n_elem, top_db);
+                     n_elem, n_frames, top_db, specmask);
   return mmsa_launch_status();
 }
 
@@ -283,5 +294,69 @@ MMSA_EXPORT int mmsa_resample_fwd(const float* pcm, int channels, long T, long s
   dim3 grid(mmsa_cdiv(frames, RS_FRAMES), batch);
   hipLaunchKernelGGL(resample_kernel, grid, dim3(256), sh, mmsa_stream(stream), pcm, channels, T, stride_b, kernT, orig,
                      nw, width, K, n_res, out, n_out);
+  return mmsa_launch_status();
+}
+
+
+// ------------------------------------------------------------------------------------------------ waveform augmentation
+// Training-time waveform augmentations of `CNN implementation/preprocess.py:56-90,137-140` for a whole batch in one
+// launch, fused with the pad / trim (`:151-156`).  The random decisions are made on the host (Python `random`, in the
+// reference's draw order) and arrive as one row of four doubles per utterance:
+//   [0] shift mode: 0 none, 1 right, 2 left      [1] shift in samples (0 with mode 1/2 silences the utterance, as the
+//   reference's empty `[:-0]` slices do)         [2] 1 = add Gaussian noise       [3] resampling factor (0 = none)
+// Composition: out[j] = aug[idx(j)], idx(j) = trunc(float(j * factor)) clamped to n_in-1 for j < ceil(n_in / factor),
+// aug[i] = shifted[i] + noise_factor * N(0,1).  The noise is a counter-based Box-Muller draw (seed, utterance, sample):
+// the same distribution as the reference's torch.randn_like, not the same stream.
+namespace {
+
+__global__ __launch_bounds__(256) void augment_wave_kernel(const float* __restrict__ in, long in_stride, int n_in,
+                                                           const double* __restrict__ params, float noise_factor,
+                                                           unsigned long long seed, float* __restrict__ out,
+                                                           int n_target) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_target) return;
+  const double* pr = params + 4 * b;
+  const int mode = (int)pr[0];
+  const long shift = (long)pr[1];
+  const bool noisy = pr[2] != 0.0;
+  const double factor = pr[3];
+  const float* x = in + (long)b * in_stride;
+  long idx = j, n_len = n_in;
+  if (factor > 0.0) {
+    n_len = (long)ceil((double)n_in / factor);
+    // torch.arange(0, n, factor) evaluates i*factor in double, stores float32; .long() truncates
+    idx = (long)(float)((double)j * factor);
+    if (idx > n_in - 1) idx = n_in - 1;
+  }
+  float v = 0.f;
+  if (j < n_len) {
+    long src = idx;
+    bool live = true;
+    if (mode == 1) { src = idx - shift; live = shift > 0 && src >= 0; }
+    if (mode == 2) { src = idx + shift; live = shift > 0 && src < n_in; }
+    if (live) v = x[src];
+    if (noisy) {
+      const unsigned long long key = ((unsigned long long)b << 32) + (unsigned long long)idx;
+      const float u1 = 1.0f - hash_uniform(seed, 2 * key), u2 = hash_uniform(seed, 2 * key + 1);   // u1 in (0,1]
+      const float gauss = sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+      {
+#pragma clang fp contract(off)   // two roundings, as `audio + noise * factor` (:78-79), not one fused multiply-add
+        const float scaled = gauss * noise_factor;
+        v = v + scaled;
+      }
+    }
+  }
+  out[(long)b * n_target + j] = v;
+}
+
+}  // namespace
+
+MMSA_EXPORT int mmsa_augment_wave(const float* in, long in_stride, int n_in, const double* params, float noise_factor,
+                                  unsigned long long seed, float* out, int n_target, int batch, void* stream) {
+  MMSA_REQUIRE(in && params && out && n_in > 0 && n_target > 0 && batch > 0 && batch <= 65535 && in_stride >= n_in);
+  dim3 grid(mmsa_cdiv(n_target, 256), batch);
+  hipLaunchKernelGGL(augment_wave_kernel, grid, dim3(256), 0, mmsa_stream(stream), in, in_stride, n_in, params,
+                     noise_factor, seed, out, n_target);
   return mmsa_launch_status();
 }

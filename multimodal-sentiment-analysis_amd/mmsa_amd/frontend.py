@@ -86,7 +86,7 @@ class LogMelFrontEnd:
         _lib.load()
         self.tables = _tables(self.device)
 
-    def __call__(self, wave: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    def __call__(self, wave: torch.Tensor, out: torch.Tensor = None, specmask: torch.Tensor = None) -> torch.Tensor:
         if wave.dim() == 1:
             wave = wave.unsqueeze(0)
         if wave.dim() != 2:
@@ -96,7 +96,9 @@ class LogMelFrontEnd:
             wave = wave.contiguous()
         if out is None:
             out = torch.empty((wave.shape[0], 1, N_MELS, N_FRAMES), dtype=torch.float32, device=self.device)
-        return ops.logmel(wave, self.tables, out, TARGET_LENGTH, TOP_DB)
+        if specmask is not None:
+            specmask = specmask.to(device=self.device, dtype=torch.int32).contiguous()
+        return ops.logmel(wave, self.tables, out, TARGET_LENGTH, TOP_DB, specmask)
 
 
 class Resampler:
@@ -192,6 +194,58 @@ class AudioTransform:
             spec[:, :, start:start + size] = 0
         return spec
 
+    # -- augmentations (whole batches on the GPU) -------------------------------------------------
+    @staticmethod
+    def draw_augmentation(n_in: int):
+        """One utterance's random decisions in the reference's draw order (preprocess.py:56-109,137-140,162-163):
+        (wave row [shift mode, shift, noise on, index step], mask row [first mel row, rows, first frame, frames]).
+        A zero shift makes the reference's slice assignment raise, which its ``__call__`` answers with an all-zero
+        map and no further draws (`:65,70,172-174`): encoded as mode != 0 with shift 0, everything else off."""
+        row, mask = [0.0, 0.0, 0.0, 0.0], [0, 0, 0, 0]
+        if random.random() >= 0.5:
+            shift = int(random.random() * 0.1 * n_in)
+            row[0] = 1.0 if random.random() > 0.5 else 2.0
+            row[1] = float(shift)
+            if shift == 0:
+                return row, mask
+        if random.random() >= 0.5:
+            row[2] = 1.0
+        if random.random() >= 0.5:
+            row[3] = random.uniform(0.9, 1.1)
+        if random.random() >= 0.5:
+            if random.random() < 0.5:
+                size = random.randint(1, 8)
+                mask[0], mask[1] = random.randint(0, N_MELS - size), size
+            if random.random() < 0.5:
+                size = random.randint(1, 8)
+                mask[2], mask[3] = random.randint(0, N_FRAMES - size), size
+        return row, mask
+
+    def augment_batch(self, waves: torch.Tensor, rows=None, masks=None, seed=None, return_wave=False):
+        """``waves [B, n]`` (mono, 22 050 Hz, un-padded) -> ``[B, 1, 64, 130]`` on the GPU: the reference's
+        augmented training transform for a whole batch in two launches (waveform augmentation + pad/trim, then the
+        mel stage with the spectral masks).  ``rows`` / ``masks`` default to fresh draws, utterance by utterance."""
+        if self._fe is None:
+            self._fe = LogMelFrontEnd(self.device)
+        dev = self._fe.device
+        waves = waves.to(device=dev, dtype=torch.float32)
+        if waves.stride(1) != 1:
+            waves = waves.contiguous()
+        B, n = waves.shape
+        if rows is None:
+            drawn = [self.draw_augmentation(n) for _ in range(B)]
+            rows, masks = [d[0] for d in drawn], [d[1] for d in drawn]
+        if seed is None:
+            # the reference consumes torch's generator for the noise (randn_like); so does the seed of ours
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        params = torch.tensor(rows, dtype=torch.float64).reshape(B, 4).to(dev)
+        out = torch.empty((B, TARGET_LENGTH), dtype=torch.float32, device=dev)
+        ops.augment_wave(waves, params, out, 0.005, seed)
+        if return_wave:
+            return out
+        mk = None if masks is None else torch.tensor(masks, dtype=torch.int32).reshape(B, 4)
+        return self._fe(out, specmask=mk)
+
     def prepare_waveform(self, audio: torch.Tensor, sr: int = SAMPLE_RATE) -> torch.Tensor:
         """Everything before the mel stage that this build covers: mono mix, resampling, augmentation, pad/trim."""
         if audio.dim() == 1:
@@ -216,14 +270,21 @@ class AudioTransform:
         return audio
 
     def __call__(self, audio, sr=SAMPLE_RATE):
+        if self.augment and not self.waveform_only:
+            # mono mix / resampling as below, then every augmentation on the GPU (waveform ones in one launch, the
+            # spectral masks inside the mel stage, ahead of the normalisation: preprocess.py:137-140,162-165)
+            if audio.dim() == 1:
+                audio = audio.unsqueeze(0)
+            if sr != SAMPLE_RATE:
+                if sr not in self._rs:
+                    self._rs[sr] = Resampler(sr, SAMPLE_RATE, self.device)
+                audio = self._rs[sr](audio, n_out=None)
+            elif audio.shape[0] > 1:
+                audio = audio.mean(dim=0, keepdim=True)
+            return self.augment_batch(audio)[0].cpu()
         wave = self.prepare_waveform(audio, sr)
         if self.waveform_only:
             return wave
-        if self.augment:
-            # the reference masks the dB map BEFORE normalising (preprocess.py:162-165); the fused kernel
-            # normalises in the same launch, so augmentation takes the unfused route below
-            raise NotImplementedError("spectral masking needs the un-normalised dB map: use waveform_only=True "
-                                      "and the batched front end for augmented training data")
         if self._fe is None:
             self._fe = LogMelFrontEnd(self.device)
         return self._fe(wave)[0].cpu()

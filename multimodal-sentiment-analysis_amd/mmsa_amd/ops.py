@@ -69,21 +69,38 @@ def _parr(ptrs: Sequence[int]):
 
 
 # ---------------------------------------------------------------------------------------------- front end
-def logmel(wave: torch.Tensor, tables, out: torch.Tensor, n_target: int = 66150, top_db: float = 80.0):
-    """wave [B, n] -> out [B, 1, 64, 1 + n_target // 512]."""
+def logmel(wave: torch.Tensor, tables, out: torch.Tensor, n_target: int = 66150, top_db: float = 80.0,
+           specmask: Optional[torch.Tensor] = None):
+    """wave [B, n] -> out [B, 1, 64, 1 + n_target // 512]; specmask [B, 4] int32 (first row, rows, first frame, frames)
+    zero-fills the dB map before normalisation."""
     if wave.dim() != 2:
         raise ValueError("wave must be [B, n_samples]")
     B, n = wave.shape
     frames = 1 + n_target // 512
     if tuple(out.shape) != (B, 1, 64, frames):
         raise ValueError(f"out must be [{B},1,64,{frames}]")
+    if specmask is not None and tuple(specmask.shape) != (B, 4):
+        raise ValueError("specmask must be [B, 4]")
     if wave.stride(1) != 1:
         raise ValueError("wave rows must be contiguous")
     if not wave.is_cuda or wave.dtype != F32:
         raise _lib.MmsaError("wave must be a float32 GPU tensor")
     _lib.call("mmsa_logmel_fwd", wave.data_ptr(), wave.stride(0), n, n_target, B, _chk(tables["window"]),
               _chk(tables["tw512"]), _chk(tables["tw1024"]), _chk(tables["melfb"]),
-              _chk(tables["melrange"], torch.int32), top_db, _chk(out), _stream())
+              _chk(tables["melrange"], torch.int32), top_db, _opt(specmask, torch.int32, "specmask"), _chk(out),
+              _stream())
+    return out
+
+
+def augment_wave(wave: torch.Tensor, params: torch.Tensor, out: torch.Tensor, noise_factor: float = 0.005,
+                 seed: int = 0):
+    """wave [B, n] + params [B, 4] float64 (shift mode, shift, noise on, index step) -> out [B, n_target]."""
+    if wave.dim() != 2 or out.dim() != 2 or wave.shape[0] != out.shape[0] or tuple(params.shape) != (wave.shape[0], 4):
+        raise ValueError("wave [B, n], params [B, 4], out [B, n_target]")
+    if not wave.is_cuda or wave.dtype != F32 or wave.stride(1) != 1:
+        raise _lib.MmsaError("wave must be a float32 GPU tensor with contiguous rows")
+    _lib.call("mmsa_augment_wave", wave.data_ptr(), wave.stride(0), wave.shape[1], _chk(params, torch.float64, "params"),
+              noise_factor, seed & ((1 << 64) - 1), _chk(out, name="out"), out.shape[1], wave.shape[0], _stream())
     return out
 
 

@@ -75,9 +75,11 @@ def logmel_f32(wave: torch.Tensor) -> torch.Tensor:
     return out.unsqueeze(1)
 
 
-def logmel_f64(wave: np.ndarray) -> np.ndarray:
+def logmel_f64(wave: np.ndarray, specmask=None) -> np.ndarray:
     """Float64 numpy evaluation of the same pipeline (fp32 filterbank values, as the reference's are
-    fp32 constants).  ``[B, 66150] -> [B, 1, 64, 130] float64``."""
+    fp32 constants).  ``[B, 66150] -> [B, 1, 64, 130] float64``.  ``specmask`` ``[B, 4]`` (first mel row,
+    rows, first frame, frames) zero-fills the dB map before normalisation, where the reference applies
+    its training-time masks (``preprocess.py:92-109,162-165``)."""
     x = np.asarray(wave, dtype=np.float64)
     if x.shape[-1] < TARGET_LEN:
         x = np.pad(x, ((0, 0), (0, TARGET_LEN - x.shape[-1])))
@@ -94,6 +96,10 @@ def logmel_f64(wave: np.ndarray) -> np.ndarray:
     mel = np.einsum("btf,fm->bmt", power, fb)
     db = 10.0 * np.log10(np.maximum(mel, AMIN))
     db = np.maximum(db, db.max(axis=(1, 2), keepdims=True) - TOP_DB)
+    if specmask is not None:
+        for b, (f0, fn, t0, tn) in enumerate(np.asarray(specmask, dtype=np.int64)):
+            db[b, f0:f0 + fn, :] = 0.0
+            db[b, :, t0:t0 + tn] = 0.0
     mean = db.mean(axis=(1, 2), keepdims=True)
     std = db.std(axis=(1, 2), keepdims=True, ddof=1)
     out = np.clip((db - mean) / (std + 1e-8), -6.0, 6.0)

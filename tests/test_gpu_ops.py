@@ -235,3 +235,64 @@ def test_text_conv_relu_maxtime():
     ra = torch.cat(args, 1)
     pos = ref > 1e-4          # where the max is a clear positive, the arg-max index must agree exactly
     assert torch.equal(arg.cpu().long()[pos], ra[pos])
+
+
+# ------------------------------------------------------------------------------------------------ augmentation
+def test_batched_augmentation_matches_oracle_draw_for_draw():
+    """Same `random` seed -> the GPU batch path and the oracle's utterance-by-utterance restatement of
+    preprocess.py:56-109,137-140,162-163 make the same decisions; with the GPU generator's own noise fed to the
+    oracle the augmented waveforms are bit-identical, and the masked, normalised maps agree to 1e-4."""
+    import random
+    from mmsa_amd import ops
+    from mmsa_amd.frontend import AudioTransform
+    from oracle import augment_ref, frontend_ref
+    B, n, seed = 24, 61000, 1234
+    g = torch.Generator().manual_seed(5)
+    waves = torch.randn(B, n, generator=g) * 0.1
+    tf = AudioTransform(augment=True, device=DEV)
+    # the generator's N(0,1) draws per (utterance, sample): noise-only pass over silence
+    only_noise = torch.tensor([[0.0, 0.0, 1.0, 0.0]] * B, dtype=torch.float64, device=DEV)
+    z = torch.empty(B, n, device=DEV)
+    ops.augment_wave(torch.zeros(B, n, device=DEV), only_noise, z, 1.0, seed)
+    z = z.cpu()
+    assert abs(float(z.mean())) < 3e-3 and abs(float(z.std()) - 1.0) < 3e-3
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.05                       # Gaussian kurtosis
+    z2 = torch.empty(B, n, device=DEV)
+    ops.augment_wave(torch.zeros(B, n, device=DEV), only_noise, z2, 1.0, seed + 1)
+    assert not torch.equal(z, z2.cpu())
+
+    random.seed(77)
+    want_w, want_m, used = [], [], set()
+    for b in range(B):
+        w, m, dropped = augment_ref.augment_utterance(waves[b].numpy(), lambda k, b=b: z[b, :k].numpy())
+        want_w.append(w)
+        want_m.append(m)
+    random.seed(77)
+    drawn = [tf.draw_augmentation(n) for _ in range(B)]
+    rows, masks = [d[0] for d in drawn], [d[1] for d in drawn]
+    assert masks == want_m
+    for r in rows:
+        used.add((r[0] != 0, r[2] != 0, r[3] != 0))
+    assert len(used) >= 6                                                 # the sample exercises the combinations
+    got_w = tf.augment_batch(waves, rows, masks, seed=seed, return_wave=True).cpu()
+    bad = [(b, rows[b]) for b in range(B) if not torch.equal(got_w[b], torch.from_numpy(want_w[b]))]
+    assert not bad, bad
+    got = tf.augment_batch(waves, rows, masks, seed=seed).cpu()
+    ref = frontend_ref.logmel_f64(np.stack(want_w), want_m)
+    check(got, torch.from_numpy(ref), 1e-4)
+    for b, m in enumerate(masks):                                         # masked cells share one value per map
+        if m[1]:
+            blk = got[b, 0, m[0]:m[0] + m[1], :]
+            assert float(blk.max() - blk.min()) == 0.0
+
+
+def test_zero_shift_drops_the_utterance_like_the_reference():
+    """A drawn shift of 0 samples makes the reference return an all-zero map (its slice assignment raises)."""
+    from mmsa_amd.frontend import AudioTransform
+    tf = AudioTransform(augment=True, device=DEV)
+    w = torch.randn(2, 30000) * 0.1
+    rows = [[1.0, 0.0, 0.0, 0.0], [2.0, 3000.0, 0.0, 1.05]]
+    out = tf.augment_batch(w, rows, [[0, 0, 0, 0]] * 2, seed=1).cpu()
+    assert torch.equal(out[0], torch.zeros_like(out[0])) and float(out[1].abs().max()) > 0
+    spec = tf(torch.randn(2, 20000) * 0.1, 16000)                          # per-utterance call, stereo 16 kHz
+    assert spec.shape == (1, 64, 130) and bool(torch.isfinite(spec).all())
