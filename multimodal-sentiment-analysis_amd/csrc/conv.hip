@@ -11,18 +11,29 @@
 //   Y[b, p, n] = sum over taps t, channels c of  X[b, p + off_t, c] * Wp[t][n][c]
 //
 // Forward / data-gradient kernel (conv_igemm): workgroup tile BM positions x BN output channels, K consumed in
-// chunks of 32 input channels of one tap; both operand tiles are staged through LDS (rows of 32 floats padded
-// to 36 so the 16-byte fragment reads are bank-conflict free) with register prefetch of the next chunk and two
-// LDS buffers (one barrier per chunk).  Each lane reads 4 consecutive k per ds_read_b128 and feeds them to 4
-// successive MFMAs; A and B use the same k permutation, so the contraction is unchanged.
+// chunks of 32 input channels of one tap.  A workgroup is eight waves with two roles: waves 4-7 only issue
+// loads, waves 0-3 only read LDS and issue MFMAs.  The loader waves bring both operand tiles from global memory
+// straight into LDS (buffer loads with an LDS destination, 1 KiB per wave instruction; positions outside the
+// image, channel tails and the padding halo use an out-of-range buffer offset, which the hardware answers with
+// zeros), several chunks ahead of the consumers in a ring of IGEMM_NBUF buffers; one barrier per chunk hands a
+// filled buffer over and takes a drained one back.  LDS rows are unpadded 128-byte runs of 32 channels; the
+// 16-byte piece a lane needs is stored at slot (piece ^ ((row >> 1) & 7)), applied on the source address because
+// the DMA's destination is lane-linear, which keeps the consumers' ds_read_b128 fragment reads conflict free.
+// Each lane reads 4 consecutive k per ds_read_b128 and feeds them to 4 successive MFMAs; A and B use the same k
+// permutation, so the contraction is unchanged.  Keeping vector-memory instructions out of the MFMA waves matters
+// on this chip: a 1 KiB load costs the issuing SIMD about as long as two MFMAs, and at least two workgroups
+// per CU are needed to cover it.
+// Optional second operand pair (conv_fwd_dual): one more tap appended to the K loop that reads another tensor
+// with weights of its own -- the shortcut's data gradient accumulated in the same launch as the 3x3 one.
 // Optional epilogue: per-tile column sums and sums of squares (the BatchNorm batch statistics and the
-// squeeze-excite global average come from these, so the raw output is not re-read).
+// squeeze-excite global average come from these, so the raw output is not re-read), stored [2][Cout][tiles].
 //
-// Weight-gradient kernel (conv_wgrad): D[cin][cout] += X[p+off][cin] * dY[p][cout] summed over positions.  In
-// channels-last layout both MFMA operands are 128-byte contiguous channel runs of one position, so lanes load
-// them straight from global memory (no LDS); each wave keeps all taps' 32x32 accumulators, the four waves of
-// a workgroup take different image rows and are combined through LDS, and workgroups write partial slabs that
-// a second kernel sums (fixed order: results are run-to-run identical) into the reference's
+// Weight-gradient kernel (conv_wgrad): D[cin][cout] += X[p+off][cin] * dY[p][cout] summed over positions.
+// A workgroup owns a (cout tile, cin tile) pair and a slab of image rows; strips of rows of X (with a zero halo)
+// and dY are staged in LDS in batches of independent 16-byte loads, operands are conflict-free ds_read_b32, the
+// four waves are (cout half) x (tap group) with accumulators living across strips, and the tap groups swap
+// between workgroups that share a CU so their LDS phases interleave.  Workgroups write partial slabs that a
+// second kernel sums (fixed order: results are run-to-run identical) into the reference's
 // [Cout][Cin][kh][kw] layout.
 #include "mmsa_common.h"
 
