@@ -59,7 +59,8 @@ def text_forward(m, input_ids: torch.Tensor, need_grad: bool, ws: Workspace):
 def text_backward(m, st, dfeat: torch.Tensor, grads: Grads):
     table = m.embedding.weight
     dtable = grads.of(table)
-    dtable.zero_()    # the kernel scatter-adds token rows into it
+    if not getattr(st, "dtable_zeroed", False):
+        dtable.zero_()    # the kernel scatter-adds token rows into it
     ops.text_bwd(dfeat.contiguous(), st.feat, st.arg, st.emb, st.ids, st.ksizes, st.wps,
                  [grads.of(c.weight) for c in m.convs], [grads.of(c.bias) for c in m.convs], dtable,
                  st.B, st.L, st.E, st.F, padding_idx=m.embedding.padding_idx if m.embedding.padding_idx is not None else -1)

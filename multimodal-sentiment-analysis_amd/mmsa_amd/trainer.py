@@ -9,16 +9,21 @@ with labels, backward, ``clip_grad_norm_(1.0)``, ``AdamW.step`` (lr / weight dec
   modality-dropout switches live in device memory, so the whole step can be captured in a HIP graph and
   replayed (``use_graph=True``) -- the reference synchronises three times per step (`:198-202`),
 * with ``torch.distributed`` initialised (one process per GPU, backend "nccl" = RCCL), utterances are sharded
-  across ranks and the flat gradient is summed with one all-reduce per bucket; the L2 term is a function of the
-  replicated parameters, so its gradient is added locally after the reduction and never communicated.
+  across ranks and the flat gradient is summed over ranks; the L2 term is a function of the replicated parameters,
+  so its gradient is added locally after the reduction and never communicated.  For modality 'both' the backward
+  is split: head and text-branch gradients (the embedding table: 87 % of the bytes) are complete before the audio
+  branch's backward starts, so their all-reduce runs on RCCL's stream underneath it; only the audio branch's
+  5 MB are reduced on the critical path.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
 
 from . import ops, parallel
+from .audio import fork
 from .model import L2_LAMBDA, MultimodalSentimentModel
 from .workspace import Grads, Workspace
 
@@ -26,7 +31,7 @@ from .workspace import Grads, Workspace
 class TrainStep:
     def __init__(self, model: MultimodalSentimentModel, lr: float = 1e-3, weight_decay: float = 1e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: Optional[float] = 1.0, frontend=None,
-                 use_graph: bool = False, process_group=None, bucket_mb: float = 16.0):
+                 use_graph: bool = False, process_group=None, bucket_mb: float = 64.0):
         self.model = model
         self.arena = model._ensure_arena()
         dev = self.arena.device
@@ -55,38 +60,79 @@ class TrainStep:
         self.dist = torch.distributed.is_available() and torch.distributed.is_initialized()
         if self.dist:
             self.world = torch.distributed.get_world_size(process_group)
-        self._buckets = parallel.make_buckets(self.g.numel(), int(bucket_mb * 1024 * 1024 / 4))
+        bucket = int(bucket_mb * 1024 * 1024 / 4)
+        self._buckets = parallel.make_buckets(self.g.numel(), bucket)
+        # overlapped exchange: [split, end) = text branch + head (ready early), [0, split) = audio branch
+        # (costs ~0.1 ms of lost concurrency inside the step, so by default only when there is somebody to talk to;
+        # MMSA_OVERLAP_ALLREDUCE=1 / 0 forces it on / off)
+        want = os.environ.get("MMSA_OVERLAP_ALLREDUCE", "auto")
+        self.overlap = self.dist and model.modality == "both" and (want == "1" or (want != "0" and self.world > 1))
+        if self.overlap:
+            n_audio = len(list(model.audio_model.parameters()))
+            split = self.arena.offsets[n_audio]
+            self._early_buckets = [(split + lo, split + hi) for lo, hi in
+                                   parallel.make_buckets(self.g.numel() - split, bucket)]
+            self._late_buckets = parallel.make_buckets(split, bucket)
         if use_graph and model.training and model._drop_p() > 0:
             raise ValueError("graph replay would repeat the same dropout masks every step; use use_graph=False "
                              "when dropout is active")
 
     # ------------------------------------------------------------------ one step's launch sequence
-    def _forward_backward(self, audio, input_ids, labels, wave):
+    def _forward_backward(self, audio, input_ids, labels, wave, phase: str = "all"):
         """Front end, forward, backward: leaves this rank's data gradient (already divided by the world size) in
-        self.g.  Pure kernel launches on the current stream: capturable."""
+        self.g.  Pure kernel launches on the current stream: capturable.  ``phase`` "early" stops after the head's
+        and the text branch's backward, "late" runs the audio branch's backward of the same step."""
         model = self.model
+        if phase == "late":
+            model._backward(self._run, None, self.grads, self.ws, phase="late")
+            return self._run.l2
         if wave is not None:
             audio = self.ws.buf("step.spec", (wave.shape[0], 1, 64, 130))
             self.frontend(wave, out=audio)
+        pre_zero = phase == "early"
+        if pre_zero:
+            # the embedding-gradient table is cleared beside the forward pass instead of ahead of the text backward,
+            # which sits on the critical path of the early exchange
+            with fork(self.ws, self.arena.device, 1):
+                self.grads.of(model.text_model.embedding.weight).zero_()
         run = model._run(audio, input_ids, labels, None, need_grad=True, ws=self.ws,
                          keep=(self.keep[0:1], self.keep[1:2]), norms_ready=self._norms_ready)
+        if pre_zero:
+            run.text.dtable_zeroed = True
         d = run.head.dlogits
         if self.world > 1:
             d.mul_(1.0 / self.world)            # sum over ranks of per-rank means -> global mean
-        model._backward(run, d, self.grads, self.ws)
+        model._backward(run, d, self.grads, self.ws, phase=phase)
+        self._run = run
         self.loss = run.loss
         self.logits = run.head.logits
         self.probs = run.head.probs
         return run.l2
 
     def _body(self, audio, input_ids, labels, wave):
-        l2 = self._forward_backward(audio, input_ids, labels, wave)
-        if self.dist:
-            self._allreduce()
+        if self.overlap:
+            l2 = self._forward_backward(audio, input_ids, labels, wave, phase="early")
+            early = self._allreduce_early()
+            self._forward_backward(audio, input_ids, labels, wave, phase="late")
+            self._allreduce_late(early)
+        else:
+            l2 = self._forward_backward(audio, input_ids, labels, wave)
+            if self.dist:
+                self._allreduce()
         self._update(l2)
 
     def _allreduce(self):
         parallel.allreduce_buckets(self.g, self._buckets, self.pg)
+
+    def _allreduce_early(self):
+        """Text-branch and head gradients: issued on the collective's stream, not waited for yet."""
+        return parallel.allreduce_buckets(self.g, self._early_buckets, self.pg, async_op=True)
+
+    def _allreduce_late(self, early):
+        """Audio-branch gradients, then make the compute stream wait for both exchanges."""
+        late = parallel.allreduce_buckets(self.g, self._late_buckets, self.pg, async_op=True)
+        for h in list(early) + list(late):
+            h.wait()
 
     def _update(self, l2: bool):
         """Clip + AdamW over the flat buffers.  self.g holds the DATA gradient only: the regulariser's gradient
@@ -143,7 +189,9 @@ class TrainStep:
             return self.loss
         # graph mode: inputs are copied into static buffers, the captured launch sequences are replayed.
         # One graph holds the whole step on a single GPU; with several ranks the step is two graphs
-        # (forward+backward, clip+AdamW) with the RCCL all-reduce issued eagerly between them.
+        # (forward+backward, clip+AdamW) with the RCCL all-reduce issued eagerly between them, or three for
+        # modality 'both' (forward + early backward | audio backward | clip+AdamW) with the first exchange
+        # running underneath the second graph.
         for k, t in ins.items():
             if t is None:
                 continue
@@ -166,18 +214,33 @@ class TrainStep:
             if not self.dist:
                 with torch.cuda.graph(g):
                     self._body(*args)
-                self._graph = (g, None)
+                self._graph = (g, None, None)
+            elif self.overlap:
+                with torch.cuda.graph(g):
+                    l2 = self._forward_backward(*args, phase="early")
+                gl = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gl, pool=g.pool()):
+                    self._forward_backward(*args, phase="late")
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2, pool=g.pool()):
+                    self._update(l2)
+                self._graph = (g, gl, g2)
             else:
                 with torch.cuda.graph(g):
                     l2 = self._forward_backward(*args)
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, pool=g.pool()):
                     self._update(l2)
-                self._graph = (g, g2)
+                self._graph = (g, None, g2)
             # capture only records: the replays below execute this step
-        g, g2 = self._graph
+        g, gl, g2 = self._graph
         g.replay()
-        if g2 is not None:
+        if gl is not None:
+            early = self._allreduce_early()
+            gl.replay()
+            self._allreduce_late(early)
+            g2.replay()
+        elif g2 is not None:
             self._allreduce()
             g2.replay()
         return self.loss

@@ -1,6 +1,8 @@
 """GPU parity of the fused training step (forward + backward + L2 term + clip + AdamW) against the oracle's
 written-out step and against the reference's own 100-step loss curve (tests/golden/loss_curves.json:
 reference model + torch.optim.AdamW + clip_grad_norm_, B=32, lr 1e-3, wd 1e-4, dropout 0, seed 42)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -146,3 +148,40 @@ def test_autograd_path_with_torch_optimizer_matches_fused_step():
             continue
         d = float(torch.linalg.vector_norm(pa.detach() - pb.detach()))
         assert d < 0.05 * 3e-3 * pa.numel() ** 0.5 + 1e-6, k      # a small fraction of three lr-sized steps
+
+
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_single_rank_process_group_path_equals_plain_step(overlap, monkeypatch):
+    """With a process group (RCCL, one rank) the step runs as several graphs with the gradient exchange issued
+    between them -- overlapped with the audio backward when overlap is on; the trajectory must equal the
+    single-graph step's."""
+    import torch.distributed as dist
+    from mmsa_amd.trainer import TrainStep
+    monkeypatch.setenv("MMSA_OVERLAP_ALLREDUCE", overlap)
+
+    def run(ts_kwargs):
+        m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+        m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+        ts = TrainStep(m, **ts_kwargs)
+        ls = []
+        for s in range(6):
+            b = batch_tensors(8 * s, 8, vocab=SMALL_VOCAB, device=DEV)
+            ls.append(ts.step(**_step_inputs("both", b)).clone())
+        torch.cuda.synchronize()
+        return ts, torch.stack(ls).cpu(), m._arena.flat.clone().cpu()
+
+    _, l_plain, p_plain = run(dict(use_graph=True))
+    port = 29600 + (os.getpid() % 200)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        for use_graph in (True, False):
+            ts, l_dist, p_dist = run(dict(use_graph=use_graph))
+            assert ts.dist and ts.overlap == (overlap == "1")
+            # run-to-run freedom: the order of the float atomic adds of repeated tokens' embedding gradients,
+            # amplified by Adam over six steps
+            assert float((l_plain - l_dist).abs().max()) < 1e-4
+            diff = float(torch.linalg.vector_norm(p_plain - p_dist))
+            assert diff < 1e-3 * float(torch.linalg.vector_norm(p_plain)), diff
+    finally:
+        dist.destroy_process_group()
