@@ -19,6 +19,7 @@ from .workspace import Grads, Workspace
 _SIDE_STREAMS = {}
 import os as _os
 FORK_WGRAD = _os.environ.get("MMSA_FORK_WGRAD", "1") != "0"
+FORK_ANY = _os.environ.get("MMSA_FORK", "1") != "0"     # 0: the whole step on one stream (diagnostics)
 
 
 def side_stream(device, which: int = 0) -> torch.cuda.Stream:
@@ -39,7 +40,7 @@ class fork:
     buffers (autograd path) everything stays on one stream."""
 
     def __init__(self, ws, device, which: int = 0, enable: bool = True):
-        self.side = side_stream(device, which) if ws.persistent and enable else None
+        self.side = side_stream(device, which) if ws.persistent and enable and FORK_ANY else None
         self.ctx = None
 
     def __enter__(self):

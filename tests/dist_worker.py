@@ -1,0 +1,77 @@
+"""Helper process of test_gpu_train.py::test_two_ranks_sharing_one_gpu: one data-parallel rank.
+
+usage: python dist_worker.py RANK WORLD PORT OUT_PREFIX USE_GRAPH
+Every rank uses cuda:0 (the test box has one GPU) and the gloo backend, which accepts GPU tensors; what is under
+test is the host logic of the multi-rank step (split backward, asynchronous exchanges, clip on the reduced gradient),
+not the transport."""
+import os
+import sys
+
+# two processes time-share one GPU's hardware queues here: with four streams each, cross-stream waits between
+# descheduled queues make progress crawl, so every rank keeps its step on one stream
+os.environ["MMSA_FORK"] = "0"
+
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from conftest import SMALL_VOCAB, batch_tensors, seeded_model  # noqa: E402
+
+
+def main():
+    import faulthandler
+    rank, world, port, prefix, use_graph = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5] == "1"
+    trace = open(f"{prefix}.rank{rank}.trace", "w")
+    faulthandler.dump_traceback_later(45, exit=True, file=trace)      # a stuck rank reports where and exits
+    # one gloo worker thread: collectives run strictly in issue order, as they do on an RCCL stream
+    opts = dist.ProcessGroupGloo._Options()
+    opts._devices = [dist.ProcessGroupGloo.create_default_device()]
+    opts._threads = 1
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                            pg_options=opts)
+    from mmsa_amd.trainer import TrainStep
+    m = seeded_model("both", vocab=SMALL_VOCAB).to("cuda").train()
+    m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+    ts = TrainStep(m, use_graph=use_graph)
+    assert ts.dist and ts.world == world and ts.overlap
+    losses = []
+    if os.environ.get("MMSA_DIST_DEBUG"):
+        import threading
+        import time
+        marks = {}
+
+        def wrap(name):
+            orig = getattr(ts, name)
+
+            def f(*a):
+                ev = torch.cuda.Event()
+                ev.record()
+                marks[name] = ev
+                print(f"rank {rank} enter {name}", file=trace, flush=True)
+                out = orig(*a)
+                print(f"rank {rank} leave {name}", file=trace, flush=True)
+                return out
+            setattr(ts, name, f)
+        wrap("_allreduce_early")
+        wrap("_allreduce_late")
+
+        def watchdog():
+            while True:
+                time.sleep(10)
+                print(f"rank {rank} watchdog: " + ", ".join(f"{k} gpu-reached={v.query()}" for k, v in marks.items()),
+                      file=trace, flush=True)
+        threading.Thread(target=watchdog, daemon=True).start()
+    for s in range(4):
+        b = batch_tensors(100 * s + 8 * rank, 8, vocab=SMALL_VOCAB, device="cuda")
+        losses.append(float(ts.step(audio=b["audio"], input_ids=b["input_ids"], labels=b["label"])))
+        print(f"rank {rank} step {s} loss {losses[-1]:.5f}", file=trace, flush=True)
+    torch.cuda.synchronize()
+    torch.save({"flat": m._arena.flat.cpu(), "losses": losses}, f"{prefix}.rank{rank}.pt")
+    dist.barrier()
+    dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
+
+
+if __name__ == "__main__":
+    main()
