@@ -135,6 +135,10 @@ MMSA_API int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const floa
                                   const float* bsum, const float* W1, const float* W2, float* d_c2, float* d_sc,
                                   float* dgamma2, float* dbeta2, float* dgammas, float* dbetas, float* dW1, float* dW2,
                                   float* scratch, int B, int H, int W, int C, int training, void* stream);
+/* dW1, dW2 may both be null in mmsa_resblock_bwd_ew: the squeeze-excite weight gradients are then left to this call
+ * (same scratch and geometry), which can run on another stream since nothing but the optimiser reads them */
+MMSA_API int mmsa_resblock_bwd_se_wgrad(const float* scratch, const float* hid, const float* gap, float* dW1,
+                                        float* dW2, int B, int H, int W, int C, void* stream);
 MMSA_API long mmsa_bn_relu_bwd_scratch_floats(long npos, int C);
 /* in place: gradient w.r.t. relu(BN(c1)) -> gradient w.r.t. c1; also dgamma, dbeta */
 MMSA_API int mmsa_bn_relu_bwd(float* dh, const float* c1, const float* coeff, float* dgamma, float* dbeta,
@@ -239,6 +243,10 @@ MMSA_API int mmsa_adamw_step(float* p, const float* g, float* m, float* v, const
                              float weight_decay, float max_norm, int do_clip, double* chunk_ss_new, void* stream);
 MMSA_API int mmsa_scale_by_state(float* g, long n, const float* state, int idx, void* stream);
 MMSA_API int mmsa_scalar_axpy(float* dst, const float* a, const float* b, float alpha, void* stream);
+/* Up to four device-to-device copies in one launch: a step's inputs into the fixed buffers that a replayed launch
+ * sequence reads (the reference moves each batch tensor with its own .to(DEVICE), multimodal_train.py:158-173).
+ * srcs / dsts / bytes are host arrays of n <= 4 entries; sizes are multiples of 4 bytes. */
+MMSA_API int mmsa_copy_multi(const void* const* srcs, void* const* dsts, const long* bytes, int n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -853,7 +853,7 @@ MMSA_EXPORT int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const f
                                      float* dW2, float* scratch, int B, int H, int W, int C, int training,
                                      void* stream) {
   MMSA_REQUIRE(dout && c2 && sc && coeff2 && coeffs && gate && hid && gap && bsum && W1 && W2 && d_c2 && d_sc);
-  MMSA_REQUIRE(dgamma2 && dbeta2 && dgammas && dbetas && dW1 && dW2 && scratch);
+  MMSA_REQUIRE(dgamma2 && dbeta2 && dgammas && dbetas && scratch && (dW1 != nullptr) == (dW2 != nullptr));
   MMSA_REQUIRE(B > 0 && H >= 2 && W >= 2 && C >= 64 && C <= 256 && C % 64 == 0);
   hipStream_t s = mmsa_stream(stream);
   const int planes = 1024 / C, chunk = planes * 4;
@@ -876,11 +876,31 @@ MMSA_EXPORT int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const f
                      dg, C, Ch);
   hipLaunchKernelGGL(rb_bwd_coeff_kernel, dim3(mmsa_cdiv(C, 64)), dim3(256), 0, s, A, gate, dg, bsum, coeff2, coeffs, B,
                      C, (float)(H * W), dgamma2, dbeta2, dgammas, dbetas, tab, training);
-  hipLaunchKernelGGL(se_wgrad_kernel, dim3(mmsa_cdiv(2L * C * Ch, 256)), dim3(256), 0, s, du, hid, dhp, gap, dW1, dW2,
-                     B, C, Ch);
+  // the squeeze-excite weight gradients feed only the optimiser: with null dW1 / dW2 they are left to
+  // mmsa_resblock_bwd_se_wgrad, which the caller may put on another stream
+  if (dW1)
+    hipLaunchKernelGGL(se_wgrad_kernel, dim3(mmsa_cdiv(2L * C * Ch, 256)), dim3(256), 0, s, du, hid, dhp, gap, dW1, dW2,
+                       B, C, Ch);
   const long total4 = (long)B * H * W * (C / 4);
   hipLaunchKernelGGL(rb_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, s, dz, c2, sc, tab, d_c2, d_sc, B,
                      (long)H * W, C);
+  return mmsa_launch_status();
+}
+
+// Gradients of the two squeeze-excite matrices from the scratch mmsa_resblock_bwd_ew left behind (same geometry,
+// same scratch pointer; valid until that scratch is written again).
+MMSA_EXPORT int mmsa_resblock_bwd_se_wgrad(const float* scratch, const float* hid, const float* gap, float* dW1,
+                                           float* dW2, int B, int H, int W, int C, void* stream) {
+  MMSA_REQUIRE(scratch && hid && gap && dW1 && dW2);
+  MMSA_REQUIRE(B > 0 && H >= 2 && W >= 2 && C >= 64 && C <= 256 && C % 64 == 0);
+  const int planes = 1024 / C, chunk = planes * 4;
+  const int P2 = (H / 2) * (W / 2);
+  const int nchunks = (P2 + chunk - 1) / chunk;
+  const int Ch = C / 16;
+  const float* du = scratch + (long)B * nchunks * 3 * C + (long)B * 3 * C;
+  const float* dhp = du + (long)B * C;
+  hipLaunchKernelGGL(se_wgrad_kernel, dim3(mmsa_cdiv(2L * C * Ch, 256)), dim3(256), 0, mmsa_stream(stream), du, hid, dhp,
+                     gap, dW1, dW2, B, C, Ch);
   return mmsa_launch_status();
 }
 

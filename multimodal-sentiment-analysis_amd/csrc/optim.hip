@@ -263,3 +263,56 @@ MMSA_EXPORT int mmsa_scalar_axpy(float* dst, const float* a, const float* b, flo
   hipLaunchKernelGGL(add_scaled_scalar_kernel, dim3(1), dim3(64), 0, mmsa_stream(stream), dst, a, b, alpha);
   return mmsa_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Up to four device-to-device copies in one launch (a step's inputs -- waveforms or spectrograms, token ids,
+// labels, the modality switches -- into the fixed buffers a replayed launch sequence reads).
+namespace {
+
+struct CopySet {
+  const unsigned* src[4];
+  unsigned* dst[4];
+  long words[4];
+};
+
+__global__ __launch_bounds__(256) void copy_multi_kernel(const CopySet cs) {
+  const int k = blockIdx.y;
+  const long n = cs.words[k];
+  const unsigned* __restrict__ s = cs.src[k];
+  unsigned* __restrict__ d = cs.dst[k];
+  const long stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if ((((unsigned long long)s | (unsigned long long)d) & 15) == 0) {
+    const long n4 = n >> 2;
+    const uint4* s4 = reinterpret_cast<const uint4*>(s);
+    uint4* d4 = reinterpret_cast<uint4*>(d);
+    for (long j = i; j < n4; j += stride) d4[j] = s4[j];
+    for (long j = (n4 << 2) + i; j < n; j += stride) d[j] = s[j];
+  } else {
+    for (; i < n; i += stride) d[i] = s[i];
+  }
+}
+
+}  // namespace
+
+// srcs / dsts: host arrays of n (<= 4) device pointers, bytes: host array of n sizes (multiples of 4)
+MMSA_EXPORT int mmsa_copy_multi(const void* const* srcs, void* const* dsts, const long* bytes, int n, void* stream) {
+  MMSA_REQUIRE(srcs && dsts && bytes && n >= 1 && n <= 4);
+  CopySet cs{};
+  long most = 0;
+  for (int k = 0; k < n; ++k) {
+    MMSA_REQUIRE(srcs[k] && dsts[k] && bytes[k] >= 0 && bytes[k] % 4 == 0);
+    MMSA_REQUIRE((((unsigned long long)srcs[k] | (unsigned long long)dsts[k]) & 3) == 0);
+    cs.src[k] = static_cast<const unsigned*>(srcs[k]);
+    cs.dst[k] = static_cast<unsigned*>(dsts[k]);
+    cs.words[k] = bytes[k] / 4;
+    if (cs.words[k] > most) most = cs.words[k];
+  }
+  if (most == 0) return MMSA_OK;
+  int blocks = (int)((most / 4 + 255) / 256);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(copy_multi_kernel, dim3(blocks, n), dim3(256), 0, mmsa_stream(stream), cs);
+  return mmsa_launch_status();
+}
+

@@ -141,13 +141,14 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
     bn2, bns = blk.bn2, blk.shortcut[1]
     ops.resblock_bwd_ew(d_out, s.c2, s.sc, s.coeff2, s.coeffs, s.gate, s.hid, s.gap, s.bsum2, W1, W2, d_c2, d_sc,
                         grads.of(bn2.weight), grads.of(bn2.bias), grads.of(bns.weight), grads.of(bns.bias),
-                        grads.of(W1), grads.of(W2), scratch, B, H, W, Cout, training)
+                        None, None, scratch, B, H, W, Cout, training)
     wsz = max(ops.conv_wgrad_workspace(B, H, W, Cout, Cout, 9), ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 9),
               ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 1))
     wg = ws.buf(name + ".wgrad_ws", wsz)
     # The three weight gradients feed nothing but the optimiser: they run on a helper stream while the data
     # gradient chain (the critical path into the previous block) continues on the main stream.
     with fork(ws, d_out.device, enable=FORK_WGRAD):                 # d_c2 / d_sc are ready
+        ops.resblock_bwd_se_wgrad(scratch, s.hid, s.gap, grads.of(W1), grads.of(W2), B, H, W, Cout)
         ops.conv_wgrad(s.h1, d_c2, grads.of(blk.conv2.weight), wg, B, H, W, Cout, Cout, ops.TAPS3X3)
         ops.conv_wgrad(s.a_in, d_sc, grads.of(blk.shortcut[0].weight), wg, B, H, W, Cin, Cout, ops.TAPS1X1)
     d_h1 = ws.buf(name + ".d_h1", (B, H, W, Cout))

@@ -335,12 +335,39 @@ def resblock_bwd_ew(dout, c2, sc, coeff2, coeffs, gate, hid, gap, bsum, W1, W2, 
     for t in (dgamma2, dbeta2, dgammas, dbetas):
         if t.numel() != C:
             raise ValueError("resblock_bwd_ew: bad BN gradient size")
-    if dW1.numel() != W1.numel() or dW2.numel() != W2.numel():
+    if (dW1 is None) != (dW2 is None):
+        raise ValueError("resblock_bwd_ew: pass both SE gradients or neither")
+    if dW1 is not None and (dW1.numel() != W1.numel() or dW2.numel() != W2.numel()):
         raise ValueError("resblock_bwd_ew: bad SE gradient size")
     _lib.call("mmsa_resblock_bwd_ew", _chk(dout), _chk(c2), _chk(sc), _chk(coeff2), _chk(coeffs), _chk(gate),
               _chk(hid), _chk(gap), _chk(bsum), _chk(W1), _chk(W2), _chk(d_c2), _chk(d_sc), _chk(dgamma2),
-              _chk(dbeta2), _chk(dgammas), _chk(dbetas), _chk(dW1), _chk(dW2), _chk(scratch), B, H, W, C,
+              _chk(dbeta2), _chk(dgammas), _chk(dbetas), _opt(dW1), _opt(dW2), _chk(scratch), B, H, W, C,
               int(training), _stream())
+
+
+def resblock_bwd_se_wgrad(scratch, hid, gap, dW1, dW2, B, H, W, C):
+    """The squeeze-excite weight gradients left out of :func:`resblock_bwd_ew` when it was called with dW1 = dW2 = None."""
+    if scratch.numel() < resblock_bwd_scratch(B, H, W, C) or dW1.numel() != dW2.numel() or dW1.numel() != C * (C // 16):
+        raise ValueError("resblock_bwd_se_wgrad: bad sizes")
+    _lib.call("mmsa_resblock_bwd_se_wgrad", _chk(scratch), _chk(hid), _chk(gap), _chk(dW1), _chk(dW2), B, H, W, C,
+              _stream())
+
+
+def copy_multi(pairs):
+    """[(dst, src), ...] (at most four; same dtype, shape and device, contiguous) copied in one launch."""
+    n = len(pairs)
+    if not 1 <= n <= 4:
+        raise ValueError("copy_multi takes one to four (dst, src) pairs")
+    srcs, dsts, sizes = [], [], []
+    for dst, src in pairs:
+        if dst.shape != src.shape or dst.dtype != src.dtype or not (dst.is_cuda and src.is_cuda) \
+                or not (dst.is_contiguous() and src.is_contiguous()):
+            raise ValueError("copy_multi: pairs must match in shape / dtype and be contiguous GPU tensors")
+        srcs.append(src.data_ptr())
+        dsts.append(dst.data_ptr())
+        sizes.append(dst.numel() * dst.element_size())
+    _lib.call("mmsa_copy_multi", (ctypes.c_void_p * n)(*srcs), (ctypes.c_void_p * n)(*dsts), (ctypes.c_long * n)(*sizes),
+              n, _stream())
 
 
 def bn_relu_bwd_scratch(npos, C) -> int:

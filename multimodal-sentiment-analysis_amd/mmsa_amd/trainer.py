@@ -148,6 +148,11 @@ class TrainStep:
                        self.eps, self.wd, self.max_norm if do_clip else 0.0, do_clip, tn, lam, emit_param_sums=l2)
         self._norms_ready = l2
 
+    @staticmethod
+    def _copy_inputs(pending):
+        for i in range(0, len(pending), 4):
+            ops.copy_multi(pending[i:i + 4])
+
     # ------------------------------------------------------------------ public API
     def step(self, audio=None, input_ids=None, labels=None, wave=None):
         """Runs one optimisation step.  Returns the device tensor holding the loss (no host sync)."""
@@ -168,9 +173,10 @@ class TrainStep:
             elif self._norms_ready and model.modality == "both":
                 # the captured sequence trusts the stored sums: refresh them once, outside the graph
                 ops.param_norms(self.arena.flat, self.arena.table, self.arena.tnorm, None, False)
+        pending = []          # (dst, src) device copies of this step's inputs: one launch for all of them
         if model.modality == "both":
             da, dt = model.fusion_layer.draw_modality_dropout()     # host RNG, audio first, as the reference
-            self.keep.copy_(self._keep_table[int(da) + 2 * int(dt)])
+            pending.append((self.keep, self._keep_table[int(da) + 2 * int(dt)]))
         dev = self.arena.device
         if wave is not None:
             audio = None
@@ -185,6 +191,7 @@ class TrainStep:
                 want = torch.int64 if k in ("input_ids", "labels") else torch.float32
                 ins[k] = t.to(device=dev, dtype=want, non_blocking=True).contiguous()
         if not self.use_graph:
+            self._copy_inputs(pending)
             self._body(ins["audio"], ins["input_ids"], ins["labels"], ins["wave"])
             return self.loss
         # graph mode: inputs are copied into static buffers, the captured launch sequences are replayed.
@@ -200,8 +207,9 @@ class TrainStep:
                 if self._graph is not None:
                     raise ValueError("graph mode needs fixed input shapes (the reference's loader uses drop_last)")
                 self._static[k] = t.clone()
-            else:
-                s.copy_(t)
+            elif s.data_ptr() != t.data_ptr():
+                pending.append((s, t))
+        self._copy_inputs(pending)
         st = self._static
         args = (st.get("audio"), st.get("input_ids"), st.get("labels"), st.get("wave"))
         if self._graph is None:
