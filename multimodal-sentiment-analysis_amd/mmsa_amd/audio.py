@@ -42,10 +42,23 @@ class fork:
     def __init__(self, ws, device, which: int = 0, enable: bool = True):
         self.side = side_stream(device, which) if ws.persistent and enable and FORK_ANY else None
         self.ctx = None
+        self.point = None
+
+    def mark(self):
+        """Fixes the fork point at the current position of the current stream; work enqueued there afterwards is
+        not waited for by the helper stream.  Lets the caller launch the critical-path kernel first: a captured
+        launch sequence tends to keep a node's first-captured successor on that node's queue."""
+        if self.side is not None:
+            self.point = torch.cuda.Event()
+            self.point.record(torch.cuda.current_stream())
+        return self
 
     def __enter__(self):
         if self.side is not None:
-            self.side.wait_stream(torch.cuda.current_stream())
+            if self.point is not None:
+                self.side.wait_event(self.point)
+            else:
+                self.side.wait_stream(torch.cuda.current_stream())
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
         return self
@@ -147,23 +160,26 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
     wg = ws.buf(name + ".wgrad_ws", wsz)
     # The three weight gradients feed nothing but the optimiser: they run on a helper stream while the data
     # gradient chain (the critical path into the previous block) continues on the main stream.
-    with fork(ws, d_out.device, enable=FORK_WGRAD):                 # d_c2 / d_sc are ready
+    # (the data-gradient kernel is launched first, the fork point having been fixed before it)
+    f2 = fork(ws, d_out.device, enable=FORK_WGRAD).mark()           # d_c2 / d_sc are ready
+    d_h1 = ws.buf(name + ".d_h1", (B, H, W, Cout))
+    ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
+    with f2:
         ops.resblock_bwd_se_wgrad(scratch, s.hid, s.gap, grads.of(W1), grads.of(W2), B, H, W, Cout)
         ops.conv_wgrad(s.h1, d_c2, grads.of(blk.conv2.weight), wg, B, H, W, Cout, Cout, ops.TAPS3X3)
         ops.conv_wgrad(s.a_in, d_sc, grads.of(blk.shortcut[0].weight), wg, B, H, W, Cin, Cout, ops.TAPS1X1)
-    d_h1 = ws.buf(name + ".d_h1", (B, H, W, Cout))
-    ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
     sc2 = ws.buf(name + ".bnrelu_scratch", ops.bn_relu_bwd_scratch(B * H * W, Cout))
     ops.bn_relu_bwd(d_h1, s.c1, s.coeff1, grads.of(blk.bn1.weight), grads.of(blk.bn1.bias), sc2, B * H * W, Cout,
                     training)
     d_c1 = d_h1
-    with fork(ws, d_out.device, enable=FORK_WGRAD):                 # d_c1 is ready
+    f1 = fork(ws, d_out.device, enable=FORK_WGRAD).mark()           # d_c1 is ready
+    d_in = None
+    if need_dx:
+        d_in = ws.buf(name + ".d_in", (B, H, W, Cin))
+        # 3x3 branch and 1x1 shortcut in one launch (one K loop over both operand pairs)
+        ops.conv_fwd_dual(d_c1, s.w1d, d_sc, s.wsd, d_in, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
+    with f1:
         ops.conv_wgrad(s.a_in, d_c1, grads.of(blk.conv1.weight), wg, B, H, W, Cin, Cout, ops.TAPS3X3)
-    if not need_dx:
-        return None
-    d_in = ws.buf(name + ".d_in", (B, H, W, Cin))
-    # 3x3 branch and 1x1 shortcut in one launch (one K loop over both operand pairs)
-    ops.conv_fwd_dual(d_c1, s.w1d, d_sc, s.wsd, d_in, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
     return d_in
 
 
