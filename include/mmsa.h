@@ -88,11 +88,14 @@ MMSA_API int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* sta
 MMSA_API int mmsa_conv_fwd_dual(const float* X, const float* Wp, const float* X2, const float* Wp2, float* Y, int B,
                                 int H, int W, int Cin, int Cout, int ntaps, const int* dh_host, const int* dw_host,
                                 void* stream);
-/* n (<= 4) convolutions of one input in one launch (the text branch's filter widths): problem i uses Wp_host[i],
- * the first ntaps_host[i] entries of the offset table and writes Y_host[i]; multimodal_model.py:186-188 */
+/* n (<= 4) convolutions of one input in one launch -- the text branch's filter widths (multimodal_model.py:186-188),
+ * or a residual block's first 3x3 convolution together with its 1x1 shortcut (:48-49,64-68): problem i uses
+ * Wp_host[i], entries tap0_host[i] .. tap0_host[i] + ntaps_host[i] - 1 of the offset table (tap0_host null: 0) and
+ * writes Y_host[i]; stats_host (null, or n pointers) receives each problem's statistics as in mmsa_conv_fwd. */
 MMSA_API int mmsa_conv_fwd_multi(const float* X, const float* const* Wp_host, float* const* Y_host,
-                                 const int* ntaps_host, int n, int B, int H, int W, int Cin, int Cout,
-                                 const int* dh_host, const int* dw_host, void* stream);
+                                 const int* ntaps_host, const int* tap0_host, float* const* stats_host, int n, int B,
+                                 int H, int W, int Cin, int Cout, int ntable, const int* dh_host, const int* dw_host,
+                                 void* stream);
 MMSA_API long mmsa_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int ntaps, int* nsplit_host);
 /* dW[Cout][Cin][ntaps] (= or +=) sum_{b,h,w} X[b,h+dh,w+dw,cin] * dY[b,h,w,cout], in two launches on one stream:
  * mmsa_conv_wgrad writes partial slabs into workspace, mmsa_conv_wgrad_reduce sums them into dW in fixed order */
@@ -119,6 +122,12 @@ MMSA_API int mmsa_stem_bwd(const float* x, const float* w, const float* bias, co
 MMSA_API int mmsa_bn_finalize(const float* partial, int rows, int tiles_per_img, double count, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, long long* nbt,
                               float momentum, float eps, int training, float* coeff, float* bsum, int C, void* stream);
+/* the same for two BatchNorm layers over maps of one geometry (host arrays of two pointers each; no bsum) */
+MMSA_API int mmsa_bn_finalize_pair(const float* const* partial_host, int rows, int tiles_per_img, double count,
+                                   const float* const* gamma_host, const float* const* beta_host,
+                                   float* const* running_mean_host, float* const* running_var_host,
+                                   long long* const* nbt_host, float momentum, float eps, int training,
+                                   float* const* coeff_host, int C, void* stream);
 MMSA_API int mmsa_bn_relu_apply(const float* x, const float* coeff, float* y, long npos, int C, void* stream);
 /* squeeze-excite gate: gap = BN(mean_hw raw), hid = relu(W1 gap), gate = sigmoid(W2 hid) */
 MMSA_API int mmsa_se_gate(const float* bsum, const float* coeff, const float* W1, const float* W2, int HW, float* gap,

@@ -249,12 +249,12 @@ __global__ __launch_bounds__(1024) void stem_bwd_w_finalize_kernel(const float* 
 // partial: [2][C][rows] sums / sums of squares (rows = B * tiles, tiles of one image contiguous).
 // One workgroup per channel: the 256 threads stride over that channel's contiguous rows (coalesced), double
 // accumulation, fixed-order combination.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int tiles_per_img,
-                                                          double count, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ rmean,
-                                                          float* __restrict__ rvar, long long* __restrict__ nbt,
-                                                          float momentum, float eps, int training,
-                                                          float* __restrict__ coeff, float* __restrict__ bsum, int C) {
+__device__ __forceinline__ void bn_finalize_body(const float* __restrict__ partial, int rows, int tiles_per_img,
+                                                 double count, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float* __restrict__ rmean,
+                                                 float* __restrict__ rvar, long long* __restrict__ nbt, float momentum,
+                                                 float eps, int training, float* __restrict__ coeff,
+                                                 float* __restrict__ bsum, int C) {
   __shared__ double red[16];
   const int c = blockIdx.x;
   if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
@@ -301,6 +301,36 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
       bsum[(long)b * C + c] = t;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int tiles_per_img,
+                                                          double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar, long long* __restrict__ nbt,
+                                                          float momentum, float eps, int training,
+                                                          float* __restrict__ coeff, float* __restrict__ bsum, int C) {
+  bn_finalize_body(partial, rows, tiles_per_img, count, gamma, beta, rmean, rvar, nbt, momentum, eps, training, coeff,
+                   bsum, C);
+}
+
+// Two BatchNorm layers over maps of the same geometry in one launch (blockIdx.y = layer): the first convolution of a
+// residual block and its shortcut.
+struct BnLayer {
+  const float* partial;
+  const float* gamma;
+  const float* beta;
+  float* rmean;
+  float* rvar;
+  long long* nbt;
+  float* coeff;
+};
+
+__global__ __launch_bounds__(256) void bn_finalize_pair_kernel(const BnLayer l0, const BnLayer l1, int rows,
+                                                               int tiles_per_img, double count, float momentum,
+                                                               float eps, int training, int C) {
+  const BnLayer& l = blockIdx.y ? l1 : l0;
+  bn_finalize_body(l.partial, rows, tiles_per_img, count, l.gamma, l.beta, l.rmean, l.rvar, l.nbt, momentum, eps,
+                   training, l.coeff, nullptr, C);
 }
 
 __global__ void bn_relu_apply_kernel(const f32x4* __restrict__ x, const float* __restrict__ coeff,
@@ -790,6 +820,24 @@ MMSA_EXPORT int mmsa_bn_finalize(const float* partial, int rows, int tiles_per_i
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, mmsa_stream(stream), partial, rows,
                      tiles_per_img, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, training, coeff,
                      bsum, C);
+  return mmsa_launch_status();
+}
+
+// The same for two layers whose maps share a geometry (arrays of two pointers each, host memory).
+MMSA_EXPORT int mmsa_bn_finalize_pair(const float* const* partial, int rows, int tiles_per_img, double count,
+                                      const float* const* gamma, const float* const* beta, float* const* running_mean,
+                                      float* const* running_var, long long* const* nbt, float momentum, float eps,
+                                      int training, float* const* coeff, int C, void* stream) {
+  MMSA_REQUIRE(partial && gamma && beta && running_mean && running_var && nbt && coeff && C > 0 && rows >= 0);
+  MMSA_REQUIRE(tiles_per_img > 0);
+  BnLayer l[2];
+  for (int i = 0; i < 2; ++i) {
+    MMSA_REQUIRE(gamma[i] && beta[i] && coeff[i]);
+    MMSA_REQUIRE(training ? (partial[i] && count > 0) : (running_mean[i] && running_var[i]));
+    l[i] = BnLayer{partial[i], gamma[i], beta[i], running_mean[i], running_var[i], nbt[i], coeff[i]};
+  }
+  hipLaunchKernelGGL(bn_finalize_pair_kernel, dim3(C, 2), dim3(256), 0, mmsa_stream(stream), l[0], l[1], rows,
+                     tiles_per_img, count, momentum, eps, training, C);
   return mmsa_launch_status();
 }
 

@@ -99,8 +99,10 @@ __global__ void pack_weights_multi_kernel(const PackDesc* __restrict__ descs) {
 struct ConvMulti {
   int n;
   int ntaps[4];
+  int tap0[4];        // problem i uses entries tap0[i] .. tap0[i] + ntaps[i] - 1 of the shared offset table
   const float* Wp[4];
   float* Y[4];
+  float* stats[4];    // per-problem statistics (STATS instantiations)
   // optional second operand pair appended to the K loop: Y += X2[b, p, :] . Wp2[:, :] (a 1x1 convolution of another
   // tensor with the same channel count, e.g. the shortcut's data gradient next to the 3x3 one)
   const float* X2;
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
   // kernel arguments are only read (never written: a modified by-value struct would be spilled to scratch)
   const bool many = multi.n > 0;   // uniform
   const int ntaps = many ? multi.ntaps[blockIdx.z] : g.ntaps;
+  const int tap0 = many ? multi.tap0[blockIdx.z] : 0;
   const float* __restrict__ Wp = many ? multi.Wp[blockIdx.z] : Wp0;
   float* __restrict__ Y = many ? multi.Y[blockIdx.z] : Y0;
   static_assert(WAVES_M * WAVES_N == 4, "4 MFMA waves per workgroup (plus 4 loader waves)");
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
     aoff[j] = (p * g.Cin + 4 * (lslot ^ ((r >> 1) & 7))) * 4;
     unsigned m = 0;
     for (int tp = 0; tp < ntaps; ++tp) {
-      const int hh = h + g.dh[tp], ww = w + g.dw[tp];
+      const int hh = h + g.dh[tap0 + tp], ww = w + g.dw[tap0 + tp];
       if (ok && hh >= 0 && hh < g.H && ww >= 0 && ww < g.W) m |= 1u << tp;
     }
     if (ok) m |= 1u << ntaps;   // the second operand's centre tap
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
   // trailing requests of the pipeline re-read that chunk harmlessly instead of branching.  The tap's offset is read
   // one chunk before it is needed (ntoff), so the scalar load is never waited for.
   int ltap = 0, lcin = 0, lcount = 0, wbuf = 0;
-  int ndh = g.dh[0], ndw = g.dw[0];
+  int ndh = g.dh[tap0], ndw = g.dw[tap0];
   // one LDS-DMA instruction of the current request: pieces 0 .. A_LD-1 are A rows, the rest B rows
 #ifndef MMSA_LAB_ABLATE
 #define MMSA_LAB_ABLATE 0   // diagnostic builds (tools/igemm_lab.hip) drop pipeline stages to price them
@@ -248,8 +251,8 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
       if (lcin == g.Cin) {
         lcin = 0;
         ++ltap;
-        ndh = g.dh[ltap];
-        ndw = g.dw[ltap];
+        ndh = g.dh[tap0 + ltap];
+        ndw = g.dw[tap0 + ltap];
       }
     }
   };
@@ -399,7 +402,8 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
 #pragma unroll
       for (int m = 0; m < WAVES_M; ++m) s += red[(m * 2 + which) * BN + col];
       // stats[2][Cout][B*tiles]: the rows of one channel are contiguous for the kernel that sums them
-      stats[((long)which * g.Cout + n0 + col) * gridDim.x + blockIdx.x] = s;
+      float* st = many ? multi.stats[blockIdx.z] : stats;
+      st[((long)which * g.Cout + n0 + col) * gridDim.x + blockIdx.x] = s;
     }
   }
   LAB_STAMP(3);
@@ -750,26 +754,33 @@ MMSA_EXPORT int mmsa_conv_fwd_dual(const float* X, const float* Wp, const float*
 }
 
 // n (<= 4) convolutions of the same input X in one launch: problem i uses packed weights Wp[i] ([ntaps[i]][Cout][Cin]),
-// the first ntaps[i] entries of the shared offset table and writes Y[i] ([B,H,W,Cout]).  Wp / Y / ntaps are host arrays.
-MMSA_EXPORT int mmsa_conv_fwd_multi(const float* X, const float* const* Wp, float* const* Y, const int* ntaps, int n,
-                                    int B, int H, int W, int Cin, int Cout, const int* dh, const int* dw, void* stream) {
+// entries tap0[i] .. tap0[i] + ntaps[i] - 1 of the shared offset table (tap0 null: every problem starts at entry 0) and
+// writes Y[i] ([B,H,W,Cout]); stats (null, or n pointers) receives each problem's per-tile column sums / sums of
+// squares in the layout of mmsa_conv_fwd.  Wp / Y / ntaps / tap0 / stats are host arrays.  ntable = entries of dh / dw.
+MMSA_EXPORT int mmsa_conv_fwd_multi(const float* X, const float* const* Wp, float* const* Y, const int* ntaps,
+                                    const int* tap0, float* const* stats, int n, int B, int H, int W, int Cin, int Cout,
+                                    int ntable, const int* dh, const int* dw, void* stream) {
   MMSA_REQUIRE(X && Wp && Y && ntaps && dh && dw && n >= 1 && n <= 4);
   MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % KC == 0 && Cout % 64 == 0);
-  int maxt = 0;
+  MMSA_REQUIRE(ntable >= 1 && ntable <= MAX_TAPS);
   ConvMulti m{};
   m.n = n;
-  for (int i = 0; i < 4; ++i) {
-    m.ntaps[i] = i < n ? ntaps[i] : 0;
-    m.Wp[i] = i < n ? Wp[i] : nullptr;
-    m.Y[i] = i < n ? Y[i] : nullptr;
-    if (i < n) {
-      MMSA_REQUIRE(ntaps[i] >= 1 && ntaps[i] <= MAX_TAPS && Wp[i] && Y[i]);
-      if (ntaps[i] > maxt) maxt = ntaps[i];
-    }
+  for (int i = 0; i < n; ++i) {
+    const int t0 = tap0 ? tap0[i] : 0;
+    MMSA_REQUIRE(ntaps[i] >= 1 && t0 >= 0 && t0 + ntaps[i] <= ntable && Wp[i] && Y[i]);
+    MMSA_REQUIRE(!stats || stats[i]);
+    m.ntaps[i] = ntaps[i];
+    m.tap0[i] = t0;
+    m.Wp[i] = Wp[i];
+    m.Y[i] = Y[i];
+    m.stats[i] = stats ? stats[i] : nullptr;
   }
   ConvGeom g;
-  if (fill_geom(g, B, H, W, Cin, Cout, maxt, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
-  return launch_igemm<64, 64, 2, 2>(X, m.Wp[0], m.Y[0], nullptr, g, 0, m, mmsa_stream(stream));
+  if (fill_geom(g, B, H, W, Cin, Cout, ntable, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
+  float* st0 = stats ? stats[0] : nullptr;
+  if (stats && pick_bm(B, H, W, Cout) == 128)
+    return launch_igemm<128, 64, 2, 2>(X, m.Wp[0], m.Y[0], st0, g, 0, m, mmsa_stream(stream));
+  return launch_igemm<64, 64, 2, 2>(X, m.Wp[0], m.Y[0], st0, g, 0, m, mmsa_stream(stream));
 }
 
 MMSA_EXPORT int mmsa_conv_pack_desc_bytes() { return (int)sizeof(PackDesc); }

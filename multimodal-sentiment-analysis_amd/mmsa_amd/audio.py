@@ -20,6 +20,12 @@ _SIDE_STREAMS = {}
 import os as _os
 FORK_WGRAD = _os.environ.get("MMSA_FORK_WGRAD", "1") != "0"
 FORK_ANY = _os.environ.get("MMSA_FORK", "1") != "0"     # 0: the whole step on one stream (diagnostics)
+# bit 0 / bit 1: launch the conv2 / conv1 data-gradient kernel ahead of the weight-gradient fork that shares its inputs
+BWD_ORDER = int(_os.environ.get("MMSA_BWD_ORDER", "3"))
+# helper streams of the weight-gradient launches: 0 one for all, 1 one per residual block, 2 one per fork
+WGRAD_STREAMS = int(_os.environ.get("MMSA_WGRAD_STREAMS", "0"))
+# 1: a block's first 3x3 convolution and its 1x1 shortcut share one launch (and one BatchNorm coefficient launch)
+FWD_PAIR = _os.environ.get("MMSA_FWD_PAIR", "1") != "0"
 
 
 def side_stream(device, which: int = 0) -> torch.cuda.Stream:
@@ -116,18 +122,39 @@ def _conv_bn(ws, name, X, wf, bn, B, H, W, Cin, Cout, taps, training, want_bsum)
     return Y, coeff, bsum
 
 
+def _conv_pair_bn(ws, name, X, w1f, wsf, bn1, bns, B, H, W, Cin, Cout, training):
+    """conv1 (3x3) and the shortcut (1x1, the centre tap of the same offset table) of a residual block in one launch,
+    then both BatchNorm coefficient sets in one launch."""
+    Y1 = ws.buf(name + ".c1.y", (B, H, W, Cout))
+    Ys = ws.buf(name + ".sc.y", (B, H, W, Cout))
+    c1 = ws.buf(name + ".c1.coeff", 4 * Cout)
+    cs = ws.buf(name + ".sc.coeff", 4 * Cout)
+    rows, tiles = ops.conv_stats_rows(B, H, W, Cout)
+    st = [ws.buf(name + ".c1.stats", rows * 2 * Cout), ws.buf(name + ".sc.stats", rows * 2 * Cout)] if training else None
+    ops.conv_fwd_multi(X, [w1f, wsf], [Y1, Ys], [9, 1], B, H, W, Cin, Cout, ops.TAPS3X3, tap0_list=[0, 4],
+                       stats_list=st)
+    ops.bn_finalize_pair(st or [None, None], rows, tiles, B * H * W, [_bn_args(bn1), _bn_args(bns)], training,
+                         [c1, cs], Cout)
+    return Y1, c1, Ys, cs
+
+
 def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: Workspace, packs):
     """One ResidualBlock + the 2x2 max-pool that follows it.  a_in: [B,H,W,Cin] -> [B,H/2,W/2,Cout]."""
     s = SimpleNamespace(B=B, H=H, W=W, Cin=Cin, Cout=Cout, a_in=a_in, name=name)
     s.w1f, s.w1d = packs[name + ".c1"]
     s.w2f, s.w2d = packs[name + ".c2"]
     s.wsf, s.wsd = packs[name + ".sc"]
-    # the 1x1 shortcut only meets the main chain at the fused add: it runs beside conv1 -> bn1 -> conv2
-    with fork(ws, a_in.device) as fsc:
-        s.sc, s.coeffs, _ = _conv_bn(ws, name + ".sc", a_in, s.wsf, blk.shortcut[1], B, H, W, Cin, Cout,
-                                     ops.TAPS1X1, training, False)
-    s.c1, s.coeff1, _ = _conv_bn(ws, name + ".c1", a_in, s.w1f, blk.bn1, B, H, W, Cin, Cout, ops.TAPS3X3, training,
-                                 False)
+    fsc = None
+    if FWD_PAIR:
+        s.c1, s.coeff1, s.sc, s.coeffs = _conv_pair_bn(ws, name, a_in, s.w1f, s.wsf, blk.bn1, blk.shortcut[1], B, H, W,
+                                                       Cin, Cout, training)
+    else:
+        # the 1x1 shortcut only meets the main chain at the fused add: it runs beside conv1 -> bn1 -> conv2
+        with fork(ws, a_in.device) as fsc:
+            s.sc, s.coeffs, _ = _conv_bn(ws, name + ".sc", a_in, s.wsf, blk.shortcut[1], B, H, W, Cin, Cout,
+                                         ops.TAPS1X1, training, False)
+        s.c1, s.coeff1, _ = _conv_bn(ws, name + ".c1", a_in, s.w1f, blk.bn1, B, H, W, Cin, Cout, ops.TAPS3X3,
+                                     training, False)
     s.h1 = ws.buf(name + ".h1", (B, H, W, Cout))
     ops.bn_relu_apply(s.c1, s.coeff1, s.h1, B * H * W, Cout)
     s.c2, s.coeff2, s.bsum2 = _conv_bn(ws, name + ".c2", s.h1, s.w2f, blk.bn2, B, H, W, Cout, Cout, ops.TAPS3X3,
@@ -139,12 +166,21 @@ def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: 
     s.gate = ws.buf(name + ".gate", (B, Cout))
     ops.se_gate(s.bsum2, s.coeff2, W1, W2, H * W, s.gap, s.hid, s.gate, B, Cout)
     s.out = ws.buf(name + ".out", (B, H // 2, W // 2, Cout))
-    fsc.join()
+    if fsc is not None:
+        fsc.join()
     ops.res_gate_relu_pool(s.c2, s.sc, s.coeff2, s.coeffs, s.gate, s.out, B, H, W, Cout)
     return s
 
 
-def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx: bool):
+def _wgrad_stream(block_index: int, second: bool) -> int:
+    if WGRAD_STREAMS == 0:
+        return 0
+    if WGRAD_STREAMS == 1:
+        return 3 + block_index
+    return 3 + 2 * block_index + int(second)
+
+
+def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx: bool, block_index: int = 0):
     """d_out: [B,H/2,W/2,Cout] -> gradient w.r.t. the block input [B,H,W,Cin] (or None)."""
     B, H, W, Cin, Cout, name = s.B, s.H, s.W, s.Cin, s.Cout, s.name
     W1, W2 = blk.se.fc[0].weight, blk.se.fc[2].weight
@@ -161,25 +197,35 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
     # The three weight gradients feed nothing but the optimiser: they run on a helper stream while the data
     # gradient chain (the critical path into the previous block) continues on the main stream.
     # (the data-gradient kernel is launched first, the fork point having been fixed before it)
-    f2 = fork(ws, d_out.device, enable=FORK_WGRAD).mark()           # d_c2 / d_sc are ready
+    f2 = fork(ws, d_out.device, _wgrad_stream(block_index, False), enable=FORK_WGRAD).mark()           # d_c2 / d_sc are ready
     d_h1 = ws.buf(name + ".d_h1", (B, H, W, Cout))
-    ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
+    if BWD_ORDER & 1:
+        ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
     with f2:
         ops.resblock_bwd_se_wgrad(scratch, s.hid, s.gap, grads.of(W1), grads.of(W2), B, H, W, Cout)
         ops.conv_wgrad(s.h1, d_c2, grads.of(blk.conv2.weight), wg, B, H, W, Cout, Cout, ops.TAPS3X3)
         ops.conv_wgrad(s.a_in, d_sc, grads.of(blk.shortcut[0].weight), wg, B, H, W, Cin, Cout, ops.TAPS1X1)
+    if not BWD_ORDER & 1:
+        ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
     sc2 = ws.buf(name + ".bnrelu_scratch", ops.bn_relu_bwd_scratch(B * H * W, Cout))
     ops.bn_relu_bwd(d_h1, s.c1, s.coeff1, grads.of(blk.bn1.weight), grads.of(blk.bn1.bias), sc2, B * H * W, Cout,
                     training)
     d_c1 = d_h1
-    f1 = fork(ws, d_out.device, enable=FORK_WGRAD).mark()           # d_c1 is ready
-    d_in = None
-    if need_dx:
-        d_in = ws.buf(name + ".d_in", (B, H, W, Cin))
+    f1 = fork(ws, d_out.device, _wgrad_stream(block_index, True), enable=FORK_WGRAD).mark()           # d_c1 is ready
+    d_in = ws.buf(name + ".d_in", (B, H, W, Cin)) if need_dx else None
+
+    def data_gradient():
         # 3x3 branch and 1x1 shortcut in one launch (one K loop over both operand pairs)
-        ops.conv_fwd_dual(d_c1, s.w1d, d_sc, s.wsd, d_in, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
+        if need_dx:
+            ops.conv_fwd_dual(d_c1, s.w1d, d_sc, s.wsd, d_in, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
+    if BWD_ORDER & 2:
+        data_gradient()
+    # (a helper stream of its own needs a slab workspace of its own)
+    wg1 = ws.buf(name + ".wgrad_ws1", wsz) if WGRAD_STREAMS == 2 else wg
     with f1:
-        ops.conv_wgrad(s.a_in, d_c1, grads.of(blk.conv1.weight), wg, B, H, W, Cin, Cout, ops.TAPS3X3)
+        ops.conv_wgrad(s.a_in, d_c1, grads.of(blk.conv1.weight), wg1, B, H, W, Cin, Cout, ops.TAPS3X3)
+    if not BWD_ORDER & 2:
+        data_gradient()
     return d_in
 
 
@@ -227,10 +273,11 @@ def audio_backward(m, st, dfeat: torch.Tensor, training: bool, grads: Grads, ws:
     B = st.B
     d = ws.buf("audio.d_last", (B, st.P, st.C))
     ops.gap_bwd(dfeat.contiguous(), d, B, st.P, st.C)
-    for blk, s in zip((m.res_block3, m.res_block2, m.res_block1), reversed(st.blocks)):
-        d = block_backward(blk, s, d, training, grads, ws, need_dx=True)
+    for i, (blk, s) in enumerate(zip((m.res_block3, m.res_block2, m.res_block1), reversed(st.blocks))):
+        d = block_backward(blk, s, d, training, grads, ws, need_dx=True, block_index=i)
     conv0, bn0 = m.conv1[0], m.conv1[1]
     scratch = ws.buf("stem.bwd_scratch", ops.stem_bwd_scratch(B, st.H))
     ops.stem_bwd(st.x, conv0.weight, conv0.bias, st.coeff0, d, grads.of(conv0.weight), grads.of(conv0.bias),
                  grads.of(bn0.weight), grads.of(bn0.bias), scratch, B, st.H, st.W, training)
-    fork(ws, dfeat.device).join()                # all weight gradients are in
+    for which in sorted({_wgrad_stream(i, sec) for i in range(3) for sec in (False, True)}):
+        fork(ws, dfeat.device, which).join()     # all weight gradients are in

@@ -213,19 +213,29 @@ def conv_fwd_dual(X, Wp, X2, Wp2, Y, B, H, W, Cin, Cout, taps, negate=False):
         ev.record()
 
 
-def conv_fwd_multi(X, Wps, Ys, ntaps_list, B, H, W, Cin, Cout, taps):
-    """Several convolutions of X in one launch; problem i uses the first ntaps_list[i] offsets of ``taps``."""
-    if X.numel() != B * H * W * Cin or len(Wps) != len(Ys) or len(Wps) != len(ntaps_list) or len(Wps) > 4:
+def conv_fwd_multi(X, Wps, Ys, ntaps_list, B, H, W, Cin, Cout, taps, tap0_list=None, stats_list=None):
+    """Several convolutions of X in one launch; problem i uses offsets tap0_list[i] .. + ntaps_list[i] of ``taps``
+    (from 0 when tap0_list is None) and, with stats_list, writes its per-tile statistics like :func:`conv_fwd`."""
+    n = len(Wps)
+    if X.numel() != B * H * W * Cin or len(Ys) != n or len(ntaps_list) != n or n > 4:
         raise ValueError("conv_fwd_multi: bad arguments")
-    for wp, y, nt in zip(Wps, Ys, ntaps_list):
-        if wp.numel() != nt * Cin * Cout or y.numel() != B * H * W * Cout or nt > len(taps):
+    tap0_list = [0] * n if tap0_list is None else list(tap0_list)
+    for wp, y, nt, t0 in zip(Wps, Ys, ntaps_list, tap0_list):
+        if wp.numel() != nt * Cin * Cout or y.numel() != B * H * W * Cout or t0 < 0 or t0 + nt > len(taps):
             raise ValueError("conv_fwd_multi: operand sizes do not match the geometry")
+    bm = 64
+    if stats_list is not None:
+        rows, _ = conv_stats_rows(B, H, W, Cout)
+        bm = _lib.query("mmsa_conv_tile_rows", B, H, W, Cout)
+        if len(stats_list) != n or any(st.numel() != rows * 2 * Cout for st in stats_list):
+            raise ValueError("conv_fwd_multi: statistics buffers have the wrong size")
     ev = None
     if PROFILE is not None:
-        ev = _prof_begin(_igemm_name(64, 64, False, False), 2.0 * B * H * W * Cin * Cout * sum(ntaps_list))
+        ev = _prof_begin(_igemm_name(bm, 64, stats_list is not None, False),
+                         2.0 * B * H * W * Cin * Cout * sum(ntaps_list))
     _lib.call("mmsa_conv_fwd_multi", _chk(X), _parr([_chk(w) for w in Wps]), _parr([_chk(y) for y in Ys]),
-              _iarr(ntaps_list), len(Wps), B, H, W, Cin, Cout, _iarr([t[0] for t in taps]),
-              _iarr([t[1] for t in taps]), _stream())
+              _iarr(ntaps_list), _iarr(tap0_list), None if stats_list is None else _parr([_chk(t) for t in stats_list]),
+              n, B, H, W, Cin, Cout, len(taps), _iarr([t[0] for t in taps]), _iarr([t[1] for t in taps]), _stream())
     if ev is not None:
         ev.record()
 
@@ -285,6 +295,19 @@ def bn_finalize(partial, rows, tiles_per_img, count, gamma, beta, rmean, rvar, n
     _lib.call("mmsa_bn_finalize", _opt(partial), rows, tiles_per_img, float(count), _chk(gamma), _chk(beta),
               _opt(rmean), _opt(rvar), _opt(nbt, torch.int64), BN_MOMENTUM, BN_EPS, int(training), _chk(coeff),
               _opt(bsum), C, _stream())
+
+
+def bn_finalize_pair(partials, rows, tiles_per_img, count, bns, training, coeffs, C):
+    """:func:`bn_finalize` for two BatchNorm layers (``bns``: (gamma, beta, running_mean, running_var, nbt) each)."""
+    if len(partials) != 2 or len(bns) != 2 or len(coeffs) != 2:
+        raise ValueError("bn_finalize_pair takes two layers")
+    for p_, bn, cf in zip(partials, bns, coeffs):
+        if cf.numel() != 4 * C or bn[0].numel() != C or (p_ is not None and p_.numel() != rows * 2 * C):
+            raise ValueError("bn_finalize_pair: bad sizes")
+    col = lambda k, dt=F32: _parr([0 if bn[k] is None else _chk(bn[k], dt) for bn in bns])   # noqa: E731
+    _lib.call("mmsa_bn_finalize_pair", _parr([0 if p_ is None else _chk(p_) for p_ in partials]), rows, tiles_per_img,
+              float(count), col(0), col(1), col(2), col(3), col(4, torch.int64), BN_MOMENTUM, BN_EPS, int(training),
+              _parr([_chk(c) for c in coeffs]), C, _stream())
 
 
 def bn_relu_apply(x, coeff, y, npos, C):
