@@ -200,11 +200,14 @@ MMSA_API int mmsa_ln_scale_bwd(const float* dy, int ldy, const float* x, const f
  *     an_dln[B,A] tn_dln[B,T] a_dspart[B] t_dspart[B] d_afeat[B,A] d_tfeat[B,T]
  *   parameter gradients (shapes of the parameters): dwpa dbpa dgpa dbepa dwpt dbpt dgpt dbept dwatt dbatt dw0 db0
  *     dg0 dbe0 dw1 db1 dg1 dbe1 dw2 db2 dan_g dan_b da_scale dtn_g dtn_b dt_scale
+ *   optional: labels[B] (int64) -- with it and dlogits set, the forward also writes
+ *     dlogits = grad_scale * (softmax(logits) - onehot(labels)) / B, the gradient of the mean cross-entropy of
+ *     multimodal_model.py:452-456, so the backward call can follow directly
  * Slots a call does not use may be null.  A, T, Hd, N0, N1 <= 512 and multiples of 4; weights 16-byte aligned.
  * Dropout (p after each projector and the first classifier layer, p/2 after the second) uses seeds seed+1..seed+4. */
 MMSA_API int mmsa_head_both_slots(void);
 MMSA_API int mmsa_head_both_fwd(const void* const* ptrs_host, int nptrs, int B, int A, int T, int Hd, int N0, int N1,
-                                int C, float drop_p, unsigned long long seed, void* stream);
+                                int C, float drop_p, unsigned long long seed, float grad_scale, void* stream);
 MMSA_API int mmsa_head_both_bwd(const void* const* ptrs_host, int nptrs, int B, int A, int T, int Hd, int N0, int N1,
                                 int C, float drop_p, unsigned long long seed, void* stream);
 MMSA_API int mmsa_head_both_bwd_params(const void* const* ptrs_host, int nptrs, int B, int A, int T, int Hd, int N0,

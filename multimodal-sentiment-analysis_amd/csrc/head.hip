@@ -31,6 +31,7 @@ enum Slot {
   S_DWPA, S_DBPA, S_DGPA, S_DBEPA, S_DWPT, S_DBPT, S_DGPT, S_DBEPT, S_DWATT, S_DBATT,
   S_DW0, S_DB0, S_DG0, S_DBE0, S_DW1, S_DB1, S_DG1, S_DBE1, S_DW2, S_DB2,
   S_DAN_G, S_DAN_B, S_DA_SCALE, S_DTN_G, S_DTN_B, S_DT_SCALE,
+  S_LABELS,   // optional (int64 [B]): the forward then also writes dlogits
   S_COUNT
 };
 
@@ -41,6 +42,7 @@ struct HeadDims {
   int B, A, T, Hd, N0, N1, C;
   float drop_p;
   unsigned long long seed;
+  float grad_scale;
 };
 
 __device__ __forceinline__ const float* cf(const HeadPtrs& h, int s) { return static_cast<const float*>(h.p[s]); }
@@ -282,6 +284,24 @@ __global__ __launch_bounds__(HT) void head_both_fwd_kernel(const HeadPtrs h, con
   matvec(cf(h, S_W2), cf(h, S_B2), s_x, s_pre, d.N1, d.C);
   __syncthreads();
   for (int n = t; n < d.C; n += HT) mf(h, S_LOGITS)[(long)b * d.C + n] = s_pre[n];
+  // with labels: the gradient of the mean cross-entropy w.r.t. this utterance's logits, (softmax - onehot) / B
+  // (multimodal_model.py:452-456 and its autograd), so the backward launch can follow without a loss kernel between
+  const long long* labels = static_cast<const long long*>(h.p[S_LABELS]);
+  float* dl = mf(h, S_DLOGITS);
+  if (labels && dl && t == 0) {
+    float m = s_pre[0];
+    for (int c = 1; c < d.C; ++c) m = fmaxf(m, s_pre[c]);
+    float sum = 0.f;
+    for (int c = 0; c < d.C; ++c) sum += expf(s_pre[c] - m);
+    const float inv = 1.0f / sum;
+    const long long y = labels[b];
+    for (int c = 0; c < d.C; ++c) {
+      const float p = expf(s_pre[c] - m) * inv;
+      float g = (p - (c == y ? 1.f : 0.f)) / (float)d.B;
+      if (d.grad_scale != 1.f) g *= d.grad_scale;
+      dl[(long)b * d.C + c] = g;
+    }
+  }
 }
 
 __global__ __launch_bounds__(HT) void head_both_bwd_kernel(const HeadPtrs h, const HeadDims d) {
@@ -444,7 +464,7 @@ __global__ __launch_bounds__(256) void head_both_wgrad_kernel(const HeadPtrs h, 
 }
 
 int fill(HeadPtrs& hp, HeadDims& hd, const void* const* ptrs, int nptrs, int first_required, int last_required, int B,
-         int A, int T, int Hd, int N0, int N1, int C, float drop_p, unsigned long long seed) {
+         int A, int T, int Hd, int N0, int N1, int C, float drop_p, unsigned long long seed, float grad_scale = 1.f) {
   if (!ptrs || nptrs != S_COUNT) return MMSA_ERR_ARG;
   if (B <= 0 || B > 65535 || A <= 0 || T <= 0 || Hd <= 0 || N0 <= 0 || N1 <= 0 || C <= 0) return MMSA_ERR_ARG;
   if (A > 512 || T > 512 || Hd > 512 || N0 > 512 || N1 > 512 || C > 512) return MMSA_ERR_LIMIT;
@@ -452,11 +472,11 @@ int fill(HeadPtrs& hp, HeadDims& hd, const void* const* ptrs, int nptrs, int fir
   if (!(drop_p >= 0.f && drop_p < 1.f)) return MMSA_ERR_ARG;
   for (int i = 0; i < S_COUNT; ++i) hp.p[i] = const_cast<void*>(ptrs[i]);
   for (int i = first_required; i <= last_required; ++i)
-    if (!hp.p[i] && i != S_KEEP_A && i != S_KEEP_T) return MMSA_ERR_ARG;
+    if (!hp.p[i] && i != S_KEEP_A && i != S_KEEP_T && i != S_LABELS) return MMSA_ERR_ARG;
   static const int weights[] = {S_WPA, S_WPT, S_WATT, S_W0, S_W1, S_W2};
   for (int s : weights)
     if (reinterpret_cast<uintptr_t>(hp.p[s]) & 15) return MMSA_ERR_ARG;
-  hd = HeadDims{B, A, T, Hd, N0, N1, C, drop_p, seed};
+  hd = HeadDims{B, A, T, Hd, N0, N1, C, drop_p, seed, grad_scale};
   return MMSA_OK;
 }
 
@@ -464,12 +484,13 @@ int fill(HeadPtrs& hp, HeadDims& hd, const void* const* ptrs, int nptrs, int fir
 
 MMSA_EXPORT int mmsa_head_both_slots() { return S_COUNT; }
 
-// Forward of the fusion head: slots a_feat .. b2 are read, slots an .. logits are written.
+// Forward of the fusion head: slots a_feat .. b2 are read, slots an .. logits are written.  With the labels and
+// dlogits slots set it also writes dlogits = grad_scale * (softmax(logits) - onehot(labels)) / B.
 MMSA_EXPORT int mmsa_head_both_fwd(const void* const* ptrs_host, int nptrs, int B, int A, int T, int Hd, int N0, int N1,
-                                   int C, float drop_p, unsigned long long seed, void* stream) {
+                                   int C, float drop_p, unsigned long long seed, float grad_scale, void* stream) {
   HeadPtrs hp;
   HeadDims hd;
-  const int rc = fill(hp, hd, ptrs_host, nptrs, S_AFEAT, S_LOGITS, B, A, T, Hd, N0, N1, C, drop_p, seed);
+  const int rc = fill(hp, hd, ptrs_host, nptrs, S_AFEAT, S_LOGITS, B, A, T, Hd, N0, N1, C, drop_p, seed, grad_scale);
   if (rc != MMSA_OK) return rc;
   hipLaunchKernelGGL(head_both_fwd_kernel, dim3(B), dim3(HT), 0, mmsa_stream(stream), hp, hd);
   return mmsa_launch_status();

@@ -75,8 +75,10 @@ def _use_layers() -> bool:
 
 
 def head_forward_both(model, a_feat, t_feat, labels, training, keep_a, keep_t, drop_p, seed, need_grad,
-                      ws: Workspace, logits_out=None):
-    """Fused path: the whole head is one launch (one workgroup per utterance) followed by softmax / CE."""
+                      ws: Workspace, logits_out=None, grad_scale: float = 1.0):
+    """Fused path: the whole head is one launch (one workgroup per utterance).  When a gradient is wanted the launch
+    also writes d(loss)/d(logits) (times ``grad_scale``), so the backward can follow at once; probabilities and the
+    loss value are then computed beside it on a helper stream.  Otherwise softmax / CE follow on this stream."""
     if _use_layers():
         return head_forward_both_layers(model, a_feat, t_feat, labels, training, keep_a, keep_t, drop_p, seed,
                                         need_grad, ws, logits_out)
@@ -113,8 +115,30 @@ def head_forward_both(model, a_feat, t_feat, labels, training, keep_a, keep_t, d
         "h2": ws.buf("head.h2", (B, N1)), "logits": logits,
     }
     st.tensors = t
-    ops.head_both("fwd", ops.head_both_table(t), st.dims, p, seed)
-    return _finish(st, ws, logits, labels, B, need_grad)
+    direct = labels is not None and need_grad
+    if direct:
+        labels = labels.contiguous()
+        if labels.dtype != torch.int64:
+            labels = labels.to(torch.int64)
+        t["labels"] = labels
+        t["dlogits"] = ws.buf("head.dlogits", (B, C))
+    ops.head_both("fwd", ops.head_both_table(t), st.dims, p, seed, grad_scale)
+    if not direct:
+        return _finish(st, ws, logits, labels, B, need_grad)
+    from .audio import fork
+    st.logits, st.dlogits, st.grad_scaled = logits, t["dlogits"], True
+    st.probs = ws.buf("head.probs", (B, C))
+    st.loss = ws.buf("head.ce", 1)
+
+    def loss_value():
+        ops.softmax_ce(logits, labels, st.probs, st.loss, None)
+    if ws.persistent:
+        # launched beside the backward (helper stream 2, after the critical-path kernels have been enqueued: a
+        # captured launch sequence keeps a node's first-captured successor on that node's queue)
+        st.deferred = [loss_value]
+    else:
+        loss_value()
+    return st
 
 
 def head_backward_both(model, st, dlogits, grads: Grads, ws: Workspace):
@@ -151,9 +175,14 @@ def head_backward_both(model, st, dlogits, grads: Grads, ws: Workspace):
     })
     table = ops.head_both_table(t)
     ops.head_both("bwd", table, st.dims, st.p, st.seed)
-    # the parameter gradients only feed the optimiser: helper stream 2 (joined at the end of the step)
-    with fork(ws, dlogits.device, 2):
-        ops.head_both("bwd_params", table, st.dims)
+    # the parameter gradients only feed the optimiser: helper stream 2 (joined at the end of the step), enqueued by
+    # the caller through st.side_work once the data-gradient chain has been launched
+    point = fork(ws, dlogits.device, 2).mark()
+
+    def param_grads():
+        with point:
+            ops.head_both("bwd_params", table, st.dims)
+    st.side_work = [param_grads]
     return t["d_afeat"], t["d_tfeat"]
 
 

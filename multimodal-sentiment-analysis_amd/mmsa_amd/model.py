@@ -355,7 +355,8 @@ class MultimodalSentimentModel(nn.Module):
         if self.modality == "both" and (audio is None or input_ids is None):
             raise ValueError("Both audio and text inputs are required for multimodal fusion")
 
-    def _run(self, audio, input_ids, labels, drops, need_grad, ws, keep=None, logits_out=None, norms_ready=False):
+    def _run(self, audio, input_ids, labels, drops, need_grad, ws, keep=None, logits_out=None, norms_ready=False,
+             grad_scale=1.0):
         """Forward launch sequence.  Returns a record with the head state, branch states and the loss buffer."""
         from types import SimpleNamespace
         arena = self._arena
@@ -364,10 +365,12 @@ class MultimodalSentimentModel(nn.Module):
         a_feat = t_feat = None
         if self.modality == "both":
             # the two branches are independent until the head: the (small) text branch runs on a helper stream
-            with audio_engine.fork(ws, arena.device, 1) as f:
-                t_feat, run.text = text_engine.text_forward(self.text_model, input_ids, need_grad, ws)
+            # (the audio chain is enqueued first: see the note on launch order in _backward)
+            f = audio_engine.fork(ws, arena.device, 1).mark()
             a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, self.audio_model.training,
                                                            need_grad, ws)
+            with f:
+                t_feat, run.text = text_engine.text_forward(self.text_model, input_ids, need_grad, ws)
             f.join()
         elif self.modality == "audio":
             a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, self.audio_model.training,
@@ -380,7 +383,7 @@ class MultimodalSentimentModel(nn.Module):
                 c = self._consts
                 keep = (c[0] if drops[0] else c[1], c[0] if drops[1] else c[1])
             run.head = head_engine.head_forward_both(self, a_feat, t_feat, labels, training, keep[0], keep[1],
-                                                     self._drop_p(), seed, need_grad, ws, logits_out)
+                                                     self._drop_p(), seed, need_grad, ws, logits_out, grad_scale)
         elif self.modality == "audio":
             run.head = head_engine.head_forward_audio(self, a_feat, labels, training, self._drop_p(), seed, need_grad,
                                                       ws, logits_out)
@@ -391,9 +394,19 @@ class MultimodalSentimentModel(nn.Module):
         if labels is not None and self.modality == "both" and run.head.loss is not None:
             run.l2 = True
             psum = ws.buf("loss.psum", 1)
-            ops.param_norms(arena.flat, arena.table, arena.tnorm, psum, norms_ready)
             run.loss = ws.buf("loss.total", 1)
-            ops.scalar_axpy(run.loss, run.head.loss, psum, L2_LAMBDA)
+            # the loss VALUE feeds nothing in the step (the regulariser's gradient is formed from the per-tensor norms
+            # inside clip / AdamW): with a gradient wanted it is computed beside the backward, on the helper stream
+            # that also carries the head's cross-entropy value and parameter gradients
+            head_loss = run.head.loss
+
+            def total_loss():
+                ops.param_norms(arena.flat, arena.table, arena.tnorm, psum, norms_ready)
+                ops.scalar_axpy(run.loss, head_loss, psum, L2_LAMBDA)
+            if need_grad and ws.persistent:
+                run.head.deferred = getattr(run.head, "deferred", []) + [total_loss]
+            else:
+                total_loss()
         if need_grad:
             run.touched = {id(p) for p in self.parameters()}
         return run
@@ -404,26 +417,47 @@ class MultimodalSentimentModel(nn.Module):
         ws = ws or Workspace(dlogits.device, persistent=False)
         if phase != "all" and self.modality != "both":
             raise ValueError("the split backward exists for modality 'both' only")
+        dev = dlogits.device if dlogits is not None else self._arena.device
+
+        def side_work():
+            """Everything that only the optimiser or the caller reads: the head's parameter gradients, then the loss
+            values, on helper stream 2."""
+            for fn in getattr(run.head, "side_work", []):
+                fn()
+            deferred = getattr(run.head, "deferred", [])
+            if deferred:
+                with audio_engine.fork(ws, dev, 2):
+                    for fn in deferred:
+                        fn()
+            run.head.side_work, run.head.deferred = [], []
+
         if phase == "early":
             run.d_audio, d_t = head_engine.head_backward_both(self, run.head, dlogits, grads, ws)
             text_engine.text_backward(self.text_model, run.text, d_t, grads)
-            audio_engine.fork(ws, dlogits.device, 2).join()
+            side_work()
+            audio_engine.fork(ws, dev, 2).join()
             return
         if phase == "late":
             audio_engine.audio_backward(self.audio_model, run.audio, run.d_audio, self.audio_model.training, grads, ws)
             return
         if self.modality == "both":
             d_a, d_t = head_engine.head_backward_both(self, run.head, dlogits, grads, ws)
-            with audio_engine.fork(ws, dlogits.device, 1) as f:
-                text_engine.text_backward(self.text_model, run.text, d_t, grads)
+            # the audio chain is the critical path: it is enqueued first, the text branch and the side work after it
+            # (each from a fork point fixed here)
+            f = audio_engine.fork(ws, dev, 1).mark()
             audio_engine.audio_backward(self.audio_model, run.audio, d_a, self.audio_model.training, grads, ws)
+            with f:
+                text_engine.text_backward(self.text_model, run.text, d_t, grads)
+            side_work()
             f.join()
         elif self.modality == "audio":
             d_a = head_engine.head_backward_audio(self, run.head, dlogits, grads, ws)
             audio_engine.audio_backward(self.audio_model, run.audio, d_a, self.audio_model.training, grads, ws)
+            side_work()
         else:
             d_t = head_engine.head_backward_text(self, run.head, dlogits, grads, ws)
             text_engine.text_backward(self.text_model, run.text, d_t, grads)
+            side_work()
         audio_engine.fork(ws, dlogits.device, 2).join()      # the head's parameter gradients (helper stream 2)
 
     # ------------------------------------------------------------------ the reference's forward signature

@@ -521,7 +521,7 @@ HEAD_SLOTS = (
     "dlogits c1_dpre c1_dln c0_dpre c0_dln att_dpre pa_dpre pa_dln pt_dpre pt_dln "
     "an_dln tn_dln a_dspart t_dspart d_afeat d_tfeat "
     "dwpa dbpa dgpa dbepa dwpt dbpt dgpt dbept dwatt dbatt dw0 db0 dg0 dbe0 dw1 db1 dg1 dbe1 dw2 db2 "
-    "dan_g dan_b da_scale dtn_g dtn_b dt_scale").split()
+    "dan_g dan_b da_scale dtn_g dtn_b dt_scale labels").split()
 
 
 def head_both_table(named: dict):
@@ -532,16 +532,20 @@ def head_both_table(named: dict):
     unknown = set(named) - set(HEAD_SLOTS)
     if unknown:
         raise KeyError(f"fused head: unknown slots {sorted(unknown)}")
-    return _parr([0 if named.get(k) is None else _chk(named[k], name=k) for k in HEAD_SLOTS])
+    return _parr([0 if named.get(k) is None else _chk(named[k], torch.int64 if k == "labels" else F32, name=k)
+                  for k in HEAD_SLOTS])
 
 
-def head_both(which: str, table, dims, drop_p=0.0, seed=0):
+def head_both(which: str, table, dims, drop_p=0.0, seed=0, grad_scale=1.0):
     """which: 'fwd' | 'bwd' | 'bwd_params'; dims = (B, A, T, Hd, N0, N1, C)."""
     if which == "bwd_params":
         _lib.call("mmsa_head_both_bwd_params", table, len(HEAD_SLOTS), *[int(d) for d in dims], _stream())
+    elif which == "fwd":
+        _lib.call("mmsa_head_both_fwd", table, len(HEAD_SLOTS), *[int(d) for d in dims], float(drop_p), int(seed),
+                  float(grad_scale), _stream())
     else:
-        _lib.call("mmsa_head_both_" + which, table, len(HEAD_SLOTS), *[int(d) for d in dims], float(drop_p),
-                  int(seed), _stream())
+        _lib.call("mmsa_head_both_bwd", table, len(HEAD_SLOTS), *[int(d) for d in dims], float(drop_p), int(seed),
+                  _stream())
 
 
 def fusion_mix_fwd(P, att, wts, fused):

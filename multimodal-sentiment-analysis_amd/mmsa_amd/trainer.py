@@ -96,11 +96,12 @@ class TrainStep:
             with fork(self.ws, self.arena.device, 1):
                 self.grads.of(model.text_model.embedding.weight).zero_()
         run = model._run(audio, input_ids, labels, None, need_grad=True, ws=self.ws,
-                         keep=(self.keep[0:1], self.keep[1:2]), norms_ready=self._norms_ready)
+                         keep=(self.keep[0:1], self.keep[1:2]), norms_ready=self._norms_ready,
+                         grad_scale=1.0 / self.world)
         if pre_zero:
             run.text.dtable_zeroed = True
         d = run.head.dlogits
-        if self.world > 1:
+        if self.world > 1 and not getattr(run.head, "grad_scaled", False):
             d.mul_(1.0 / self.world)            # sum over ranks of per-rank means -> global mean
         model._backward(run, d, self.grads, self.ws, phase=phase)
         self._run = run
