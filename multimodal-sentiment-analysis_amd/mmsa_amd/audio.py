@@ -26,7 +26,6 @@ BWD_ORDER = int(_os.environ.get("MMSA_BWD_ORDER", "3"))
 WGRAD_STREAMS = int(_os.environ.get("MMSA_WGRAD_STREAMS", "0"))
 # 1: a block's first 3x3 convolution and its 1x1 shortcut share one launch (and one BatchNorm coefficient launch)
 FWD_PAIR = _os.environ.get("MMSA_FWD_PAIR", "1") != "0"
-KEEPWARM = int(_os.environ.get("MMSA_KEEPWARM", "0"))
 
 
 def side_stream(device, which: int = 0) -> torch.cuda.Stream:
@@ -261,23 +260,14 @@ def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Works
     with fpack:
         packs = pack_all(m, need_grad, ws)
     fpack.join()
-    warm = []
     for i, blk in enumerate((m.res_block1, m.res_block2, m.res_block3)):
         cout = blk.conv1.weight.shape[0]
-        fk = fork(ws, x.device).mark() if KEEPWARM and need_grad else None
         s = block_forward(blk, f"rb{i + 1}", a, B, h, w, cin, cout, training, need_grad, ws, packs)
-        if fk is not None and (KEEPWARM >> i) & 1:
-            dummy = ws.buf("audio.keepwarm", 4)
-            with fk:
-                ops.scalar_axpy(dummy[0:1], dummy[1:2], dummy[2:3], 0.0)
-            warm.append(fk)
         st.blocks.append(s)
         a, h, w, cin = s.out, h // 2, w // 2, cout
     st.P, st.C = h * w, cin
     feat = ws.buf("audio.feat", (B, cin))
     ops.gap_fwd(a, feat, B, st.P, cin)
-    for fk in warm:
-        fk.join()
     return feat, st
 
 

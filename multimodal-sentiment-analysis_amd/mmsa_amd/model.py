@@ -442,13 +442,12 @@ class MultimodalSentimentModel(nn.Module):
             return
         if self.modality == "both":
             d_a, d_t = head_engine.head_backward_both(self, run.head, dlogits, grads, ws)
-            # the audio chain is the critical path: it is enqueued first, the text branch and the side work after it
-            # (each from a fork point fixed here)
-            f = audio_engine.fork(ws, dev, 1).mark()
-            audio_engine.audio_backward(self.audio_model, run.audio, d_a, self.audio_model.training, grads, ws)
-            with f:
+            # launch order matters under graph replay: the short text branch and the side work are enqueued first (they
+            # then start at once on helper queues), the audio chain after them
+            with audio_engine.fork(ws, dev, 1) as f:
                 text_engine.text_backward(self.text_model, run.text, d_t, grads)
             side_work()
+            audio_engine.audio_backward(self.audio_model, run.audio, d_a, self.audio_model.training, grads, ws)
             f.join()
         elif self.modality == "audio":
             d_a = head_engine.head_backward_audio(self, run.head, dlogits, grads, ws)
