@@ -103,6 +103,12 @@ MMSA_API int mmsa_conv_wgrad(const float* X, const float* dY, float* workspace, 
                              int Cin, int Cout, int ntaps, const int* dh_host, const int* dw_host, void* stream);
 MMSA_API int mmsa_conv_wgrad_reduce(const float* workspace, float* dW, int B, int H, int W, int Cin, int Cout,
                                     int ntaps, int accumulate, void* stream);
+/* both weight gradients that read a residual block's input X (3x3 convolution from dY9, 1x1 shortcut from dY1;
+ * multimodal_model.py:48-49,64-68 under autograd) in one launch plus one reduction launch; ws9 / ws1 as sized by
+ * mmsa_conv_wgrad_workspace_floats for 9 and 1 taps */
+MMSA_API int mmsa_conv_wgrad_pair(const float* X, const float* dY9, const float* dY1, float* ws9, float* ws1,
+                                  float* dW9, float* dW1, int B, int H, int W, int Cin, int Cout, const int* dh_host,
+                                  const int* dw_host, void* stream);
 
 /* ---- audio branch, bandwidth-bound parts: multimodal_model.py:78-83 (stem), :27-42 (SEBlock), :64-70
  *      (ResidualBlock tail), :87-96,118-127 (pools, global average). ----------------------------------------- */

@@ -418,9 +418,10 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
 // instead and each half writes its own slab.  Accumulators stay in registers across strips; each workgroup
 // writes one partial slab [tap][Cin][Cout] (two for 1x1), summed in fixed order by wgrad_reduce_kernel.
 template <int NT>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
-                                                            float* __restrict__ partial, ConvGeom g, int R, int nstrips,
-                                                            int strips_per_img) {
+__device__ __forceinline__ void conv_wgrad_body(const float* __restrict__ X, const float* __restrict__ dY,
+                                                float* __restrict__ partial, const ConvGeom& g, int R, int nstrips,
+                                                int strips_per_img, int nsplit) {
+  if ((int)blockIdx.y >= nsplit) return;   // uniform (a paired launch sizes the grid for the larger problem)
   constexpr int MAXT = NT == 1 ? 1 : (NT + 1) / 2;
   extern __shared__ float lds[];
   const int WP = g.W + 2;
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
   unsigned long long lab_t0 = __builtin_amdgcn_s_memtime(), lab_load = 0, lab_comp = 0, lab_t;
   const unsigned long long lab_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  for (int strip = blockIdx.y; strip < nstrips; strip += gridDim.y) {
+  for (int strip = blockIdx.y; strip < nstrips; strip += nsplit) {
 #ifdef MMSA_LAB_STAMPS
     lab_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -569,16 +570,40 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
 #endif
 }
 
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dY,
+                                                            float* __restrict__ partial, ConvGeom g, int R, int nstrips,
+                                                            int strips_per_img) {
+  conv_wgrad_body<NT>(X, dY, partial, g, R, nstrips, strips_per_img, (int)gridDim.y);
+}
+
+// The 3x3 and the 1x1 weight gradient of a residual block's two input convolutions (same input X, different output
+// gradients) in one launch: blockIdx.z selects the problem, each with its own strip plan.
+struct WgradArgs {
+  const float* dY;
+  float* partial;
+  int R, nstrips, strips_per_img, nsplit;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_pair_kernel(const float* __restrict__ X, const ConvGeom g9,
+                                                                 const ConvGeom g1, const WgradArgs a9,
+                                                                 const WgradArgs a1) {
+  if (blockIdx.z == 0)
+    conv_wgrad_body<9>(X, a9.dY, a9.partial, g9, a9.R, a9.nstrips, a9.strips_per_img, a9.nsplit);
+  else
+    conv_wgrad_body<1>(X, a1.dY, a1.partial, g1, a1.R, a1.nstrips, a1.strips_per_img, a1.nsplit);
+}
+
 // partial[slab][tap][Cin][Cout] -> dW[Cout][Cin][ntaps]  (+= when accumulate).  64 outputs per workgroup, the
 // NW (4 or 16, by the number of slabs) waves take interleaved slabs (four independent loads each per round) and are combined in fixed order
 // through LDS.
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW,
-                                                               int nslabs, int ntaps, int Cin, int Cout, int accumulate) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partial, float* __restrict__ dW, int nslabs,
+                                                  int ntaps, int Cin, int Cout, int accumulate, long block) {
   __shared__ float red[NW][64];
   const long total = (long)ntaps * Cin * Cout;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long i = (long)blockIdx.x * 64 + lane;
+  const long i = block * 64 + lane;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < total) {
     int k = w;
@@ -603,6 +628,25 @@ __global__ __launch_bounds__(NW * 64) void wgrad_reduce_kernel(const float* __re
     float* dst = dW + ((long)co * Cin + ci) * ntaps + tp;
     *dst = accumulate ? (*dst + s) : s;
   }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dW,
+                                                               int nslabs, int ntaps, int Cin, int Cout, int accumulate) {
+  wgrad_reduce_body<NW>(partial, dW, nslabs, ntaps, Cin, Cout, accumulate, (long)blockIdx.x);
+}
+
+// the reductions of a paired launch: the first blocks9 workgroups sum the 3x3 slabs, the rest the 1x1 slabs
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad_reduce_pair_kernel(const float* __restrict__ partial9,
+                                                                    float* __restrict__ dW9, int nslabs9,
+                                                                    const float* __restrict__ partial1,
+                                                                    float* __restrict__ dW1, int nslabs1, int blocks9,
+                                                                    int Cin, int Cout) {
+  if ((int)blockIdx.x < blocks9)
+    wgrad_reduce_body<NW>(partial9, dW9, nslabs9, 9, Cin, Cout, 0, (long)blockIdx.x);
+  else
+    wgrad_reduce_body<NW>(partial1, dW1, nslabs1, 1, Cin, Cout, 0, (long)blockIdx.x - blocks9);
 }
 
 struct WgradPlan {
@@ -832,6 +876,41 @@ MMSA_EXPORT int mmsa_conv_wgrad(const float* X, const float* dY, float* workspac
     hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), p.shmem, s, X, dY, workspace, g, p.R, p.nstrips,
                        p.strips_per_img);
   }
+  return mmsa_launch_status();
+}
+
+// Both weight gradients that read a residual block's input X in one launch pair: dW9[Cout][Cin][9] from dY9 (the 3x3
+// convolution, offsets dh / dw) and dW1[Cout][Cin][1] from dY1 (the 1x1 shortcut).  ws9 / ws1 are the slab workspaces of
+// mmsa_conv_wgrad_workspace_floats for 9 and 1 taps; results are identical to two separate mmsa_conv_wgrad +
+// mmsa_conv_wgrad_reduce sequences.
+MMSA_EXPORT int mmsa_conv_wgrad_pair(const float* X, const float* dY9, const float* dY1, float* ws9, float* ws1,
+                                     float* dW9, float* dW1, int B, int H, int W, int Cin, int Cout, const int* dh,
+                                     const int* dw, void* stream) {
+  MMSA_REQUIRE(X && dY9 && dY1 && ws9 && ws1 && dW9 && dW1 && dh && dw);
+  MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && Cin % 32 == 0 && Cout % 64 == 0 && Cin > 0 && Cout > 0);
+  for (int i = 0; i < 9; ++i) MMSA_REQUIRE(dh[i] >= -1 && dh[i] <= 1 && dw[i] >= -1 && dw[i] <= 1);
+  ConvGeom g9, g1;
+  const int zero = 0;
+  if (fill_geom(g9, B, H, W, Cin, Cout, 9, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
+  if (fill_geom(g1, B, H, W, Cin, Cout, 1, &zero, &zero) != MMSA_OK) return MMSA_ERR_ARG;
+  const WgradPlan p9 = plan_wgrad(B, H, W, Cin, Cout, 9), p1 = plan_wgrad(B, H, W, Cin, Cout, 1);
+  const size_t shmem = p9.shmem > p1.shmem ? p9.shmem : p1.shmem;
+  MMSA_REQUIRE(shmem <= 150 * 1024);
+  hipStream_t s = mmsa_stream(stream);
+  if (shmem > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pair_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
+    return MMSA_ERR_LAUNCH;
+  const WgradArgs a9{dY9, ws9, p9.R, p9.nstrips, p9.strips_per_img, p9.nsplit};
+  const WgradArgs a1{dY1, ws1, p1.R, p1.nstrips, p1.strips_per_img, p1.nsplit};
+  dim3 grid((Cin / 32) * (Cout / 64), p9.nsplit > p1.nsplit ? p9.nsplit : p1.nsplit, 2);
+  hipLaunchKernelGGL(conv_wgrad_pair_kernel, grid, dim3(256), shmem, s, X, g9, g1, a9, a1);
+  const int blocks9 = (int)((9L * Cin * Cout + 63) / 64), blocks1 = (int)(((long)Cin * Cout + 63) / 64);
+  if (p9.nslabs > 64 || p1.nslabs > 64)
+    hipLaunchKernelGGL(wgrad_reduce_pair_kernel<16>, dim3(blocks9 + blocks1), dim3(1024), 0, s, ws9, dW9, p9.nslabs, ws1,
+                       dW1, p1.nslabs, blocks9, Cin, Cout);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_pair_kernel<4>, dim3(blocks9 + blocks1), dim3(256), 0, s, ws9, dW9, p9.nslabs, ws1,
+                       dW1, p1.nslabs, blocks9, Cin, Cout);
   return mmsa_launch_status();
 }
 

@@ -26,6 +26,8 @@ BWD_ORDER = int(_os.environ.get("MMSA_BWD_ORDER", "3"))
 WGRAD_STREAMS = int(_os.environ.get("MMSA_WGRAD_STREAMS", "0"))
 # 1: a block's first 3x3 convolution and its 1x1 shortcut share one launch (and one BatchNorm coefficient launch)
 FWD_PAIR = _os.environ.get("MMSA_FWD_PAIR", "1") != "0"
+# 1: the weight gradients of conv1 and of the shortcut (both read the block input) share one launch
+WGRAD_PAIR = _os.environ.get("MMSA_WGRAD_PAIR", "1") != "0"
 
 
 def side_stream(device, which: int = 0) -> torch.cuda.Stream:
@@ -204,7 +206,8 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
     with f2:
         ops.resblock_bwd_se_wgrad(scratch, s.hid, s.gap, grads.of(W1), grads.of(W2), B, H, W, Cout)
         ops.conv_wgrad(s.h1, d_c2, grads.of(blk.conv2.weight), wg, B, H, W, Cout, Cout, ops.TAPS3X3)
-        ops.conv_wgrad(s.a_in, d_sc, grads.of(blk.shortcut[0].weight), wg, B, H, W, Cin, Cout, ops.TAPS1X1)
+        if not WGRAD_PAIR:
+            ops.conv_wgrad(s.a_in, d_sc, grads.of(blk.shortcut[0].weight), wg, B, H, W, Cin, Cout, ops.TAPS1X1)
     if not BWD_ORDER & 1:
         ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
     sc2 = ws.buf(name + ".bnrelu_scratch", ops.bn_relu_bwd_scratch(B * H * W, Cout))
@@ -223,7 +226,12 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
     # (a helper stream of its own needs a slab workspace of its own)
     wg1 = ws.buf(name + ".wgrad_ws1", wsz) if WGRAD_STREAMS == 2 else wg
     with f1:
-        ops.conv_wgrad(s.a_in, d_c1, grads.of(blk.conv1.weight), wg1, B, H, W, Cin, Cout, ops.TAPS3X3)
+        if WGRAD_PAIR:
+            wgs = ws.buf(name + ".wgrad_ws_sc", ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 1))
+            ops.conv_wgrad_pair(s.a_in, d_c1, grads.of(blk.conv1.weight), d_sc, grads.of(blk.shortcut[0].weight), wg1,
+                                wgs, B, H, W, Cin, Cout)
+        else:
+            ops.conv_wgrad(s.a_in, d_c1, grads.of(blk.conv1.weight), wg1, B, H, W, Cin, Cout, ops.TAPS3X3)
     if not BWD_ORDER & 2:
         data_gradient()
     return d_in

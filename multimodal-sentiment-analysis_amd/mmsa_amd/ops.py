@@ -259,6 +259,22 @@ def conv_wgrad(X, dY, dW, workspace, B, H, W, Cin, Cout, taps, w_valid=None, acc
               _stream())
 
 
+def conv_wgrad_pair(X, dY9, dW9, dY1, dW1, ws9, ws1, B, H, W, Cin, Cout, taps=None):
+    """dW9 (3x3, from dY9) and dW1 (1x1, from dY1) of two convolutions of the same input X: one launch + one reduction."""
+    taps = TAPS3X3 if taps is None else taps
+    n = B * H * W
+    if X.numel() != n * Cin or dY9.numel() != n * Cout or dY1.numel() != n * Cout or dW9.numel() != 9 * Cin * Cout \
+            or dW1.numel() != Cin * Cout or len(taps) != 9:
+        raise ValueError("conv_wgrad_pair: operand sizes do not match the geometry")
+    if ws9.numel() < conv_wgrad_workspace(B, H, W, Cin, Cout, 9) or ws1.numel() < conv_wgrad_workspace(B, H, W, Cin, Cout, 1):
+        raise ValueError("conv_wgrad_pair: workspace too small")
+    ev = _prof_begin("conv_wgrad_kernel<9>", 2.0 * n * Cin * Cout * 10)
+    _lib.call("mmsa_conv_wgrad_pair", _chk(X), _chk(dY9), _chk(dY1), _chk(ws9), _chk(ws1), _chk(dW9), _chk(dW1), B, H, W,
+              Cin, Cout, _iarr([t[0] for t in taps]), _iarr([t[1] for t in taps]), _stream())
+    if ev is not None:
+        ev.record()
+
+
 # ---------------------------------------------------------------------------------------------- audio branch
 def stem_stats(x, w, bias, partial, B, H, W):
     if x.numel() != B * H * W or partial.numel() != B * H * 64 or w.numel() != 288 or bias.numel() != 32:

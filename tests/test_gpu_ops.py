@@ -296,3 +296,24 @@ def test_zero_shift_drops_the_utterance_like_the_reference():
     assert torch.equal(out[0], torch.zeros_like(out[0])) and float(out[1].abs().max()) > 0
     spec = tf(torch.randn(2, 20000) * 0.1, 16000)                          # per-utterance call, stereo 16 kHz
     assert spec.shape == (1, 64, 130) and bool(torch.isfinite(spec).all())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 8, 16, 128, 256), (2, 32, 65, 32, 64), (4, 16, 32, 64, 128)])
+def test_paired_weight_gradients_equal_separate_launches(B, H, W, Cin, Cout):
+    """The 3x3 and 1x1 weight gradients of one input computed in one launch are bit-identical to the two separate
+    launch sequences (same strip plans, same fixed-order slab sums)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 1000 + W)
+    X = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+    dY9 = torch.randn(B, H, W, Cout, generator=g).to(DEV)
+    dY1 = torch.randn(B, H, W, Cout, generator=g).to(DEV)
+    ws9 = torch.empty(ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 9), device=DEV)
+    ws1 = torch.empty(ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 1), device=DEV)
+    a9, a1 = torch.empty(Cout, Cin, 3, 3, device=DEV), torch.empty(Cout, Cin, 1, 1, device=DEV)
+    ops.conv_wgrad(X, dY9, a9, ws9, B, H, W, Cin, Cout, ops.TAPS3X3)
+    ops.conv_wgrad(X, dY1, a1, ws1, B, H, W, Cin, Cout, ops.TAPS1X1)
+    b9, b1 = torch.full_like(a9, 7.0), torch.full_like(a1, 7.0)
+    ws9.fill_(3.0)
+    ws1.fill_(3.0)
+    ops.conv_wgrad_pair(X, dY9, b9, dY1, b1, ws9, ws1, B, H, W, Cin, Cout)
+    assert torch.equal(a9, b9) and torch.equal(a1, b1)
