@@ -46,6 +46,25 @@ def main():
         gbs = B * 297880 / t / 1e9
         out[f"frontend_B{B}"] = {"us": round(t * 1e6, 1), "utt_per_s": round(B / t), "GB_per_s": round(gbs, 1),
                                  "frac_of_hbm_peak": round(gbs / HBM_PEAK, 4)}
+    # resampler 16 kHz -> 22.05 kHz: 48 000 samples in, 66 150 out per utterance (4 B each), 334 taps per output
+    from mmsa_amd.frontend import AudioTransform, Resampler
+    rs = Resampler(16000, 22050, DEV)
+    for B in (32, 1024):
+        pcm = torch.randn(B, 1, 48000, device=DEV) * 0.1
+        res = torch.empty(B, 66150, device=DEV)
+        t = timeit(lambda: rs(pcm, out=res))
+        gbs = B * (48000 + 66150) * 4 / t / 1e9
+        out[f"resample16k_B{B}"] = {"us": round(t * 1e6, 1), "utt_per_s": round(B / t), "GB_per_s": round(gbs, 1),
+                                    "frac_of_hbm_peak": round(gbs / HBM_PEAK, 4),
+                                    "tflops": round(B * 66150 * 334 * 2 / t / 1e12, 2)}
+    # augmented training transform for a batch (waveform augmentation + mel stage with masks)
+    tf = AudioTransform(augment=True, device=DEV)
+    for B in (32, 1024):
+        wave = torch.randn(B, 66150, device=DEV) * 0.1
+        drawn = [tf.draw_augmentation(66150) for _ in range(B)]
+        rows, masks = [d[0] for d in drawn], [d[1] for d in drawn]
+        t = timeit(lambda: tf.augment_batch(wave, rows, masks, seed=1))
+        out[f"augment_batch_B{B}"] = {"us": round(t * 1e6, 1), "utt_per_s": round(B / t)}
     # embedding gather: 1 KiB read + 1 KiB written per token
     table = torch.randn(30522, 256, device=DEV)
     for B in (32, 4096):
