@@ -60,8 +60,8 @@ MMSA_API int mmsa_augment_wave(const float* in, long in_stride, int n_in, const 
                                unsigned long long seed, float* out, int n_target, int batch, void* stream);
 /* Resampling ahead of the mel stage: torchaudio.transforms.Resample's sinc interpolation (Hann window,
  * lowpass_filter_width 6, rolloff 0.99) as applied at preprocess.py:131-134, fused with the mono mix (:127-129) and
- * the pad / trim to n_out samples (:151-156).  mmsa_resample_filters_host builds the filter bank kernT[K][new] on the
- * host (null kernT: size query); mmsa_resample_fwd maps pcm [batch][channels][T] to out [batch][n_out]. */
+ * the pad / trim to n_out samples (:151-156).  mmsa_resample_filters_host builds the filter bank kernT[K][ld] on the
+ * host (ld = new rounded up to a multiple of 4, padding zero, 16-byte aligned on the device; null kernT: size query); mmsa_resample_fwd maps pcm [batch][channels][T] to out [batch][n_out]. */
 MMSA_API int mmsa_resample_filters_host(int orig_freq, int new_freq, int lowpass_filter_width, double rolloff,
                                         float* kernT, int* orig_out, int* new_out, int* width_out, int* K_out);
 MMSA_API int mmsa_resample_fwd(const float* pcm, int channels, long T, long stride_b, const float* kernT, int orig,

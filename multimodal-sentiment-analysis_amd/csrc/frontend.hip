@@ -210,17 +210,22 @@ MMSA_EXPORT int mmsa_logmel_fwd(const float* wave, long wave_stride, int n_valid
 // zero-padded input window starting at sample i*orig - width.
 namespace {
 
-constexpr int RS_FRAMES = 4;   // input strides (of `orig` samples) per workgroup
+constexpr int RS_FRAMES = 8;    // input strides (of `orig` samples) per workgroup
+constexpr int RS_THREADS = 512;
 
-__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ pcm, int channels, long T,
-                                                       long stride_b, const float* __restrict__ kernT, int orig, int nw,
-                                                       int width, int K, long n_res, float* __restrict__ out, int n_out) {
+// Work item = four consecutive output phases of two consecutive frames: per tap one 16-byte read of the filter bank
+// (rows padded to `ld` floats, a multiple of 4, so the read is aligned; the bank stays in L2) and two LDS reads feed
+// eight multiply-adds.  The sum over taps runs in tap order with fused multiply-adds.
+__global__ __launch_bounds__(RS_THREADS) void resample_kernel(const float* __restrict__ pcm, int channels, long T,
+                                                              long stride_b, const float* __restrict__ kernT, int ld,
+                                                              int orig, int nw, int width, int K, long n_res,
+                                                              float* __restrict__ out, int n_out) {
   extern __shared__ float win[];   // mono-mixed, zero-padded input window of RS_FRAMES strides plus the filter tail
   const int b = blockIdx.y;
   const long i0 = (long)blockIdx.x * RS_FRAMES;
   const int nwin = RS_FRAMES * orig + K;
   const float* src = pcm + (long)b * stride_b;
-  for (int i = threadIdx.x; i < nwin; i += 256) {
+  for (int i = threadIdx.x; i < nwin; i += RS_THREADS) {
     const long n = i0 * orig + i - width;
     float v = 0.f;
     if (n >= 0 && n < T) {
@@ -230,16 +235,32 @@ __global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__
     win[i] = v;
   }
   __syncthreads();
-  for (int o = threadIdx.x; o < RS_FRAMES * nw; o += 256) {
-    const int fr = o / nw, p = o - fr * nw;
-    const long j = (i0 + fr) * nw + p;        // output sample
-    if (j >= n_out) continue;
-    float acc = 0.f;
-    if (j < n_res) {
-      const float* x = win + fr * orig;
-      for (int k = 0; k < K; ++k) acc = fmaf(kernT[(long)k * nw + p], x[k], acc);
+  const int groups = (nw + 3) >> 2;
+  for (int item = threadIdx.x; item < groups * (RS_FRAMES / 2); item += RS_THREADS) {
+    const int fp = item / groups, pg = item - fp * groups;
+    const int p = 4 * pg;
+    const float* x0 = win + (2 * fp) * orig;
+    const float* x1 = x0 + orig;
+    const float* kp = kernT + p;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(kp + (long)k * ld);
+      const float u = x0[k], v = x1[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a0[e] = fmaf(w[e], u, a0[e]);
+        a1[e] = fmaf(w[e], v, a1[e]);
+      }
     }
-    out[(long)b * n_out + j] = acc;           // samples past the resampled length are the zero padding
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const long jbase = (i0 + 2 * fp + f) * nw + p;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long j = jbase + e;            // output sample
+        if (p + e < nw && j < n_out) out[(long)b * n_out + j] = j < n_res ? (f ? a1[e] : a0[e]) : 0.f;
+      }
+    }
   }
 }
 
@@ -248,9 +269,9 @@ long rs_gcd(long a, long b) { while (b) { const long t = a % b; a = b; b = t; } 
 }  // namespace
 
 // Filter bank of the resampler, built on the host in double precision (torchaudio's construction) and stored
-// transposed, kernT[K][new], so that consecutive output phases read consecutive floats.  Returns through the out
-// parameters the reduced rates, the one-sided filter width and the tap count K = 2*width + orig; kernT may be null
-// to query the sizes first.
+// transposed, kernT[K][ld] with ld = new rounded up to a multiple of 4 (padding zero), so that consecutive output
+// phases read consecutive floats in aligned 16-byte pieces.  Returns through the out parameters the reduced rates, the
+// one-sided filter width and the tap count K = 2*width + orig; kernT may be null to query the sizes first.
 MMSA_EXPORT int mmsa_resample_filters_host(int orig_freq, int new_freq, int lowpass_filter_width, double rolloff,
                                            float* kernT, int* orig_out, int* new_out, int* width_out, int* K_out) {
   MMSA_REQUIRE(orig_freq > 0 && new_freq > 0 && lowpass_filter_width > 0 && rolloff > 0.0 && rolloff <= 1.0);
@@ -264,6 +285,8 @@ MMSA_EXPORT int mmsa_resample_filters_host(int orig_freq, int new_freq, int lowp
   if (!kernT) return MMSA_OK;
   const double pi = 3.14159265358979323846, lpw = (double)lowpass_filter_width;
   const double scale = base / orig;
+  const int ld = (nw + 3) & ~3;
+  for (long i = 0; i < (long)K * ld; ++i) kernT[i] = 0.f;
   for (int p = 0; p < nw; ++p)
     for (int k = 0; k < K; ++k) {
       double t = (-(double)p / nw + (double)(k - width) / orig) * base;
@@ -273,7 +296,7 @@ MMSA_EXPORT int mmsa_resample_filters_host(int orig_freq, int new_freq, int lowp
       const double window = c * c;
       t *= pi;
       const double s = t == 0.0 ? 1.0 : sin(t) / t;
-      kernT[(long)k * nw + p] = (float)(s * window * scale);
+      kernT[(long)k * ld + p] = (float)(s * window * scale);
     }
   return MMSA_OK;
 }
@@ -284,6 +307,8 @@ MMSA_EXPORT int mmsa_resample_fwd(const float* pcm, int channels, long T, long s
                                   int nw, int width, int K, float* out, int n_out, int batch, void* stream) {
   MMSA_REQUIRE(pcm && kernT && out && channels > 0 && T > 0 && batch > 0 && batch <= 65535 && n_out > 0);
   MMSA_REQUIRE(orig > 0 && nw > 0 && width > 0 && K == 2 * width + orig && stride_b >= (long)channels * T);
+  MMSA_REQUIRE((reinterpret_cast<uintptr_t>(kernT) & 15) == 0);
+  const int ld = (nw + 3) & ~3;
   const size_t sh = (size_t)(RS_FRAMES * orig + K) * sizeof(float);
   if (sh > 150 * 1024) return MMSA_ERR_LIMIT;
   if (sh > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(resample_kernel),
@@ -292,8 +317,8 @@ MMSA_EXPORT int mmsa_resample_fwd(const float* pcm, int channels, long T, long s
   const long n_res = ((long)nw * T + orig - 1) / orig;
   const int frames = mmsa_cdiv(n_out, nw);
   dim3 grid(mmsa_cdiv(frames, RS_FRAMES), batch);
-  hipLaunchKernelGGL(resample_kernel, grid, dim3(256), sh, mmsa_stream(stream), pcm, channels, T, stride_b, kernT, orig,
-                     nw, width, K, n_res, out, n_out);
+  hipLaunchKernelGGL(resample_kernel, grid, dim3(RS_THREADS), sh, mmsa_stream(stream), pcm, channels, T, stride_b, kernT,
+                     ld, orig, nw, width, K, n_res, out, n_out);
   return mmsa_launch_status();
 }
 

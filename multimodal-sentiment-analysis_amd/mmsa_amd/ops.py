@@ -110,7 +110,7 @@ def resample_filters(orig_freq: int, new_freq: int, device, lowpass_filter_width
     ptrs = [ctypes.cast(ctypes.byref(geo, 4 * i), ctypes.c_void_p) for i in range(4)]
     _lib.call("mmsa_resample_filters_host", orig_freq, new_freq, lowpass_filter_width, rolloff, None, *ptrs)
     orig, new, width, K = (int(v) for v in geo)
-    host = torch.empty((K, new), dtype=F32)
+    host = torch.empty((K, (new + 3) // 4 * 4), dtype=F32)      # rows padded to a multiple of 4 floats
     _lib.call("mmsa_resample_filters_host", orig_freq, new_freq, lowpass_filter_width, rolloff, host.data_ptr(), *ptrs)
     return {"kernT": host.to(device), "orig": orig, "new": new, "width": width, "K": K}
 

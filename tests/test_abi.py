@@ -54,11 +54,13 @@ def test_resample_filter_bank_matches_oracle_and_has_unit_dc_gain():
         _lib.call("mmsa_resample_filters_host", sr, 22050, 6, 0.99, None, *ptrs)
         orig, new, width, K = (int(v) for v in geo)
         assert (orig, new, width, K) == want
-        kern_t = np.zeros((K, new), np.float32)
+        ld = (new + 3) // 4 * 4                                  # rows are padded to 16-byte multiples
+        kern_t = np.ones((K, ld), np.float32)
         _lib.call("mmsa_resample_filters_host", sr, 22050, 6, 0.99, kern_t.ctypes.data_as(ctypes.c_void_p), *ptrs)
         filt, w, o, n = resample_ref.sinc_filters(sr, 22050)
         assert (o, n, w) == (orig, new, width) and filt.shape == (new, K)
-        np.testing.assert_allclose(kern_t.T, filt, rtol=0, atol=2e-7)
+        np.testing.assert_allclose(kern_t[:, :new].T, filt, rtol=0, atol=2e-7)
+        assert not kern_t[:, new:].any()
         # every output phase passes DC at the gain of a windowed sinc cut just below Nyquist
         assert np.abs(filt.sum(1) - 1.0).max() < 2e-3
     lib = _lib.load()
