@@ -39,6 +39,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace {
 
 constexpr int MAX_TAPS = 9;
@@ -506,37 +508,47 @@ __device__ __forceinline__ void conv_wgrad_body(const float* __restrict__ X, con
 #ifdef MMSA_LAB_STAMPS
     { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); lab_load += n_ - lab_t; lab_t = n_; }
 #endif
-    // One MFMA step covers two positions (k = lane half).  Operands of step s+1 are read from LDS before the MFMAs
-    // of step s issue, so the LDS latency hides behind the matrix pipe.  For odd W the last step's second
-    // position does not exist: its dY operand is zero and its X address is clamped.
+    // One MFMA step covers two positions (k = lane half).  Two operand sets alternate: the LDS reads of step s+1 go
+    // out before the MFMAs of step s and are first used a whole step later, so their latency hides behind the matrix
+    // pipe.  Past the end of a row (odd W, or the extra step of an odd step count) the dY operand is zero and the X
+    // address is clamped.  The loop is specialised on the wave's tap count (5 or 4 of the nine taps; 1 for 1x1).
     const int nsteps = (g.W + 1) >> 1;
-    for (int r = (NT == 1 ? q : 0); r < R; r += (NT == 1 ? 2 : 1)) {
-      const float* yrow = Ys + (r * g.W) * 64 + jt * 32 + li;
-      const float* xrow = Xs + ((r + 1) * WP + 1) * 32 + li;
-      float dy, a[MAXT];
-      {
-        const bool v = kk < g.W;
-        const int wc = v ? kk : g.W - 1;
-        dy = v ? yrow[wc * 64] : 0.f;
+    auto rows = [&](auto tc_tag) {
+      constexpr int TC = decltype(tc_tag)::value;
+      for (int r = (NT == 1 ? q : 0); r < R; r += (NT == 1 ? 2 : 1)) {
+        const float* yrow = Ys + (r * g.W) * 64 + jt * 32 + li;
+        const float* xrow = Xs + ((r + 1) * WP + 1) * 32 + li;
+        float dy0, dy1, a0[TC], a1[TC];
+        auto fetch = [&](int st, float& dy, float (&a)[TC]) {
+          const int w = 2 * st + kk;
+          const bool v = w < g.W;
+          const int wc = v ? w : g.W - 1;
+          dy = 0.f;
+          if (v) dy = yrow[wc * 64];
 #pragma unroll
-        for (int i = 0; i < MAXT; ++i) a[i] = xrow[wc * 32 + toff[i]];
+          for (int i = 0; i < TC; ++i) a[i] = xrow[wc * 32 + toff[i]];
+        };
+        auto fma_step = [&](const float dy, const float (&a)[TC]) {
+#pragma unroll
+          for (int i = 0; i < TC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], dy, acc[i], 0, 0, 0);
+        };
+        fetch(0, dy0, a0);
+        for (int st = 0; st < nsteps; st += 2) {
+          fetch(st + 1, dy1, a1);
+          __builtin_amdgcn_sched_barrier(0);
+          fma_step(dy0, a0);
+          __builtin_amdgcn_sched_barrier(0);
+          fetch(st + 2, dy0, a0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (st + 1 < nsteps) fma_step(dy1, a1);   // uniform
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      for (int st = 0; st < nsteps; ++st) {
-        const int w = 2 * (st + 1) + kk;
-        const bool v = w < g.W;
-        const int wc = v ? w : g.W - 1;
-        const float ndy = v ? yrow[wc * 64] : 0.f;
-        float na[MAXT];
-#pragma unroll
-        for (int i = 0; i < MAXT; ++i) na[i] = xrow[wc * 32 + toff[i]];
-#pragma unroll
-        for (int i = 0; i < MAXT; ++i)
-          if (i < t_count) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], dy, acc[i], 0, 0, 0);
-        dy = ndy;
-#pragma unroll
-        for (int i = 0; i < MAXT; ++i) a[i] = na[i];
-      }
-    }
+    };
+    if (NT == 1 || t_count == MAXT)
+      rows(std::integral_constant<int, MAXT>{});
+    else
+      rows(std::integral_constant<int, (NT == 1 ? 1 : NT - MAXT)>{});
 #ifdef MMSA_LAB_STAMPS
     { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); lab_comp += n_ - lab_t; }
 #endif

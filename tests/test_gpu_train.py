@@ -104,7 +104,7 @@ def test_graph_replay_equals_eager():
     # same kernels, same order; the only run-to-run freedom is the order of the float atomic adds that scatter
     # repeated tokens' embedding gradients, so agreement is to rounding, not bitwise
     # (Adam then turns a last-bit difference in a noise-level gradient into a different +-lr step for that element)
-    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-5
+    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-4
     diff = float(torch.linalg.vector_norm(res[0][1] - res[1][1]))
     assert diff < 1e-3 * float(torch.linalg.vector_norm(res[0][1])), diff
 
