@@ -1,4 +1,4 @@
-"""Attention-fusion head over pooled backbone features (BASELINE config 4).
+"""Attention-fusion head over pooled backbone features (the reference's `Pretrained model implementations/early_fusion.py` head).
 
 Mirrors `Pretrained model implementations/early_fusion.py`: ``AttentionFusionLayer`` (`:83-158`: per-modality
 Linear + LayerNorm, a shared tanh attention MLP scoring the two projections, softmax over the two scores, sigmoid

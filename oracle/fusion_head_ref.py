@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the attention-fusion head (BASELINE config 4).
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of the attention-fusion head (the reference's `Pretrained model implementations/early_fusion.py` head).
 
 PARITY UNPINNED beyond torch.nn itself: the reference module (`Pretrained model implementations/early_fusion.py`)
 cannot be imported here (its imports need librosa / torchaudio / seaborn and remote HuggingFace weights) and ships no

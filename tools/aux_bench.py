@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Secondary measurements on one MI355X: the bandwidth-bound kernels against the HBM roofline and the inference
-configuration (BASELINE config 5: --modality both, batch 1024, eval).  Prints one JSON object.
+configuration of the reference's test script (--modality both, batch 1024, eval).  Prints one JSON object.
 
     python tools/aux_bench.py
 """
