@@ -89,7 +89,8 @@ def main():
     from mmsa_amd.trainer import TrainStep
 
     torch.manual_seed(42)
-    model = MultimodalSentimentModel("both", audio_dropout=0.0, text_dropout=0.0, fusion_dropout=0.0).to(dev).train()
+    # the training driver's defaults (multimodal_train.py:71-76,457-468): dropout 0.5 / 0.3 / 0.6, modality dropout 0.3
+    model = MultimodalSentimentModel("both", audio_dropout=0.5, text_dropout=0.3, fusion_dropout=0.6).to(dev).train()
     fe = LogMelFrontEnd(dev)
     use_graph = not args.no_graph
     ts = TrainStep(model, lr=1e-3, weight_decay=1e-4, max_norm=1.0, frontend=fe, use_graph=use_graph)
@@ -170,7 +171,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "CNN --modality both train step (log-mel front end + fwd + bwd + L2 term + clip 1.0 "
                                    "+ AdamW lr 1e-3 wd 1e-4), batch 32/GPU, 3 s @ 22.05 kHz waveforms, 128 tokens, "
-                                   "vocab 30522, dropout 0", "global_batch": world * PER_GPU_BATCH,
+                                   "vocab 30522, fusion dropout 0.6, modality dropout 0.3", "global_batch": world * PER_GPU_BATCH,
                        "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}",
                        "launch": "hip-graph replay" if use_graph else "eager"},
             "model_tflops": round(value * TRAIN_FLOP_PER_UTT / 1e12, 2),

@@ -208,7 +208,9 @@ MMSA_API int mmsa_ln_scale_bwd(const float* dy, int ldy, const float* x, const f
  *     dg0 dbe0 dw1 db1 dg1 dbe1 dw2 db2 dan_g dan_b da_scale dtn_g dtn_b dt_scale
  *   optional: labels[B] (int64) -- with it and dlogits set, the forward also writes
  *     dlogits = grad_scale * (softmax(logits) - onehot(labels)) / B, the gradient of the mean cross-entropy of
- *     multimodal_model.py:452-456, so the backward call can follow directly
+ *     multimodal_model.py:452-456, so the backward call can follow directly;
+ *     step[1] (float) -- a device-resident step counter: forward and backward add step[0] * 0x9E3779B97F4A7C15 to
+ *     the seed, so a replayed launch sequence draws new dropout masks every step
  * Slots a call does not use may be null.  A, T, Hd, N0, N1 <= 512 and multiples of 4; weights 16-byte aligned.
  * Dropout (p after each projector and the first classifier layer, p/2 after the second) uses seeds seed+1..seed+4. */
 MMSA_API int mmsa_head_both_slots(void);

@@ -32,6 +32,7 @@ enum Slot {
   S_DW0, S_DB0, S_DG0, S_DBE0, S_DW1, S_DB1, S_DG1, S_DBE1, S_DW2, S_DB2,
   S_DAN_G, S_DAN_B, S_DA_SCALE, S_DTN_G, S_DTN_B, S_DT_SCALE,
   S_LABELS,   // optional (int64 [B]): the forward then also writes dlogits
+  S_STEP,     // optional (float [1]): a device-resident step counter mixed into the dropout seed
   S_COUNT
 };
 
@@ -46,6 +47,12 @@ struct HeadDims {
 };
 
 __device__ __forceinline__ const float* cf(const HeadPtrs& h, int s) { return static_cast<const float*>(h.p[s]); }
+// Dropout seed of this launch: the host's seed, advanced by the device-resident step counter when there is one, so
+// that a replayed launch sequence (whose scalar arguments are frozen) still draws fresh masks every step.
+__device__ __forceinline__ unsigned long long step_seed(const HeadPtrs& h, unsigned long long seed) {
+  const float* step = static_cast<const float*>(h.p[S_STEP]);
+  return step ? seed + (unsigned long long)step[0] * 0x9E3779B97F4A7C15ull : seed;
+}
 __device__ __forceinline__ float* mf(const HeadPtrs& h, int s) { return static_cast<float*>(h.p[s]); }
 
 // out[n] = bias[n] + sum_k W[n][k] x[k] for n < N (x, out in LDS; K a multiple of 4, rows of W 16-byte aligned).
@@ -216,6 +223,7 @@ __global__ __launch_bounds__(HT) void head_both_fwd_kernel(const HeadPtrs h, con
   __shared__ __attribute__((aligned(16))) float s_x[512];      // fused / hidden vectors
   const int b = blockIdx.x, t = threadIdx.x;
   const int A = d.A, T = d.T, Hd = d.Hd;
+  const unsigned long long seed = step_seed(h, d.seed);
 
   // feature normaliser: LayerNorm * scale * modality keep flag
   for (int n = t; n < A; n += HT) s_pre[n] = cf(h, S_AFEAT)[(long)b * A + n];
@@ -248,9 +256,9 @@ __global__ __launch_bounds__(HT) void head_both_fwd_kernel(const HeadPtrs h, con
   __syncthreads();
   float* Pg = mf(h, S_P) + (long)b * 2 * Hd;
   ln_relu_drop(s_pre, Hd, cf(h, S_GPA), cf(h, S_BEPA), s_P, Pg, mf(h, S_PA_PRE), mf(h, S_PA_STATS), b, d.drop_p,
-               d.seed + 1);
+               seed + 1);
   ln_relu_drop(s_pre + 512, Hd, cf(h, S_GPT), cf(h, S_BEPT), s_P + Hd, Pg + Hd, mf(h, S_PT_PRE), mf(h, S_PT_STATS), b,
-               d.drop_p, d.seed + 2);
+               d.drop_p, seed + 2);
 
   // attention over the two modalities and the weighted sum
   matvec(cf(h, S_WATT), cf(h, S_BATT), s_P, s_pre, 2 * Hd, 2);
@@ -276,11 +284,11 @@ __global__ __launch_bounds__(HT) void head_both_fwd_kernel(const HeadPtrs h, con
   matvec(cf(h, S_W0), cf(h, S_B0), s_x, s_pre, Hd, d.N0);
   __syncthreads();
   ln_relu_drop(s_pre, d.N0, cf(h, S_G0), cf(h, S_BE0), s_x, mf(h, S_H1) + (long)b * d.N0, mf(h, S_C0_PRE),
-               mf(h, S_C0_STATS), b, d.drop_p, d.seed + 3);
+               mf(h, S_C0_STATS), b, d.drop_p, seed + 3);
   matvec(cf(h, S_W1), cf(h, S_B1), s_x, s_pre, d.N0, d.N1);
   __syncthreads();
   ln_relu_drop(s_pre, d.N1, cf(h, S_G1), cf(h, S_BE1), s_x, mf(h, S_H2) + (long)b * d.N1, mf(h, S_C1_PRE),
-               mf(h, S_C1_STATS), b, 0.5f * d.drop_p, d.seed + 4);
+               mf(h, S_C1_STATS), b, 0.5f * d.drop_p, seed + 4);
   matvec(cf(h, S_W2), cf(h, S_B2), s_x, s_pre, d.N1, d.C);
   __syncthreads();
   for (int n = t; n < d.C; n += HT) mf(h, S_LOGITS)[(long)b * d.C + n] = s_pre[n];
@@ -311,16 +319,17 @@ __global__ __launch_bounds__(HT) void head_both_bwd_kernel(const HeadPtrs h, con
   __shared__ float part[HT];
   const int b = blockIdx.x, t = threadIdx.x;
   const int A = d.A, T = d.T, Hd = d.Hd, N0 = d.N0, N1 = d.N1, C = d.C;
+  const unsigned long long seed = step_seed(h, d.seed);
 
   // logits layer (plain Linear): its dPre is the incoming gradient itself
   for (int n = t; n < C; n += HT) s_g[n] = cf(h, S_DLOGITS)[(long)b * C + n];
   __syncthreads();
   matvec_t(cf(h, S_W2), s_g, s_d, part, N1, C, false);
   ln_relu_drop_bwd(s_d, s_g, part, N1, cf(h, S_C1_PRE), cf(h, S_C1_STATS), cf(h, S_G1), cf(h, S_BE1),
-                   mf(h, S_C1_DLN), mf(h, S_C1_DPRE), b, 0.5f * d.drop_p, d.seed + 4);
+                   mf(h, S_C1_DLN), mf(h, S_C1_DPRE), b, 0.5f * d.drop_p, seed + 4);
   matvec_t(cf(h, S_W1), s_g, s_d, part, N0, N1, false);
   ln_relu_drop_bwd(s_d, s_g, part, N0, cf(h, S_C0_PRE), cf(h, S_C0_STATS), cf(h, S_G0), cf(h, S_BE0),
-                   mf(h, S_C0_DLN), mf(h, S_C0_DPRE), b, d.drop_p, d.seed + 3);
+                   mf(h, S_C0_DLN), mf(h, S_C0_DPRE), b, d.drop_p, seed + 3);
   matvec_t(cf(h, S_W0), s_g, s_d, part, Hd, N0, false);      // s_d = d fused
 
   // weighted sum and the softmax over the two attention scores
@@ -348,10 +357,10 @@ __global__ __launch_bounds__(HT) void head_both_bwd_kernel(const HeadPtrs h, con
 
   // projectors, then the feature normaliser
   ln_relu_drop_bwd(s_dP, s_g, part, Hd, cf(h, S_PA_PRE), cf(h, S_PA_STATS), cf(h, S_GPA), cf(h, S_BEPA),
-                   mf(h, S_PA_DLN), mf(h, S_PA_DPRE), b, d.drop_p, d.seed + 1);
+                   mf(h, S_PA_DLN), mf(h, S_PA_DPRE), b, d.drop_p, seed + 1);
   matvec_t(cf(h, S_WPA), s_g, s_d, part, A, Hd, false);       // s_d[0..A) = d an
   ln_relu_drop_bwd(s_dP + Hd, s_g, part, Hd, cf(h, S_PT_PRE), cf(h, S_PT_STATS), cf(h, S_GPT), cf(h, S_BEPT),
-                   mf(h, S_PT_DLN), mf(h, S_PT_DPRE), b, d.drop_p, d.seed + 2);
+                   mf(h, S_PT_DLN), mf(h, S_PT_DPRE), b, d.drop_p, seed + 2);
   matvec_t(cf(h, S_WPT), s_g, s_d + 512, part, T, Hd, false);  // s_d[512..512+T) = d tn
 
 #pragma unroll 1
@@ -472,7 +481,7 @@ int fill(HeadPtrs& hp, HeadDims& hd, const void* const* ptrs, int nptrs, int fir
   if (!(drop_p >= 0.f && drop_p < 1.f)) return MMSA_ERR_ARG;
   for (int i = 0; i < S_COUNT; ++i) hp.p[i] = const_cast<void*>(ptrs[i]);
   for (int i = first_required; i <= last_required; ++i)
-    if (!hp.p[i] && i != S_KEEP_A && i != S_KEEP_T && i != S_LABELS) return MMSA_ERR_ARG;
+    if (!hp.p[i] && i != S_KEEP_A && i != S_KEEP_T && i != S_LABELS && i != S_STEP) return MMSA_ERR_ARG;
   static const int weights[] = {S_WPA, S_WPT, S_WATT, S_W0, S_W1, S_W2};
   for (int s : weights)
     if (reinterpret_cast<uintptr_t>(hp.p[s]) & 15) return MMSA_ERR_ARG;

@@ -75,10 +75,12 @@ def _use_layers() -> bool:
 
 
 def head_forward_both(model, a_feat, t_feat, labels, training, keep_a, keep_t, drop_p, seed, need_grad,
-                      ws: Workspace, logits_out=None, grad_scale: float = 1.0):
+                      ws: Workspace, logits_out=None, grad_scale: float = 1.0, step_state=None):
     """Fused path: the whole head is one launch (one workgroup per utterance).  When a gradient is wanted the launch
     also writes d(loss)/d(logits) (times ``grad_scale``), so the backward can follow at once; probabilities and the
-    loss value are then computed beside it on a helper stream.  Otherwise softmax / CE follow on this stream."""
+    loss value are then computed beside it on a helper stream.  Otherwise softmax / CE follow on this stream.
+    ``step_state`` (a one-element float tensor holding the optimiser's step count) is mixed into the dropout seed on
+    the device, which is what lets a replayed launch sequence draw new masks every step."""
     if _use_layers():
         return head_forward_both_layers(model, a_feat, t_feat, labels, training, keep_a, keep_t, drop_p, seed,
                                         need_grad, ws, logits_out)
@@ -114,6 +116,8 @@ def head_forward_both(model, a_feat, t_feat, labels, training, keep_a, keep_t, d
         "c1_pre": ws.buf("head.c1.pre", (B, N1)), "c1_stats": ws.buf("head.c1.stats", 2 * B),
         "h2": ws.buf("head.h2", (B, N1)), "logits": logits,
     }
+    if step_state is not None and p > 0:
+        t["step"] = step_state
     st.tensors = t
     direct = labels is not None and need_grad
     if direct:

@@ -356,7 +356,7 @@ class MultimodalSentimentModel(nn.Module):
             raise ValueError("Both audio and text inputs are required for multimodal fusion")
 
     def _run(self, audio, input_ids, labels, drops, need_grad, ws, keep=None, logits_out=None, norms_ready=False,
-             grad_scale=1.0):
+             grad_scale=1.0, step_state=None):
         """Forward launch sequence.  Returns a record with the head state, branch states and the loss buffer."""
         from types import SimpleNamespace
         arena = self._arena
@@ -383,7 +383,7 @@ class MultimodalSentimentModel(nn.Module):
                 c = self._consts
                 keep = (c[0] if drops[0] else c[1], c[0] if drops[1] else c[1])
             run.head = head_engine.head_forward_both(self, a_feat, t_feat, labels, training, keep[0], keep[1],
-                                                     self._drop_p(), seed, need_grad, ws, logits_out, grad_scale)
+                                                     self._drop_p(), seed, need_grad, ws, logits_out, grad_scale, step_state)
         elif self.modality == "audio":
             run.head = head_engine.head_forward_audio(self, a_feat, labels, training, self._drop_p(), seed, need_grad,
                                                       ws, logits_out)

@@ -537,7 +537,7 @@ HEAD_SLOTS = (
     "dlogits c1_dpre c1_dln c0_dpre c0_dln att_dpre pa_dpre pa_dln pt_dpre pt_dln "
     "an_dln tn_dln a_dspart t_dspart d_afeat d_tfeat "
     "dwpa dbpa dgpa dbepa dwpt dbpt dgpt dbept dwatt dbatt dw0 db0 dg0 dbe0 dw1 db1 dg1 dbe1 dw2 db2 "
-    "dan_g dan_b da_scale dtn_g dtn_b dt_scale labels").split()
+    "dan_g dan_b da_scale dtn_g dtn_b dt_scale labels step").split()
 
 
 def head_both_table(named: dict):

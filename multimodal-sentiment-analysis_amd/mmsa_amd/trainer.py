@@ -73,7 +73,10 @@ class TrainStep:
             self._early_buckets = [(split + lo, split + hi) for lo, hi in
                                    parallel.make_buckets(self.g.numel() - split, bucket)]
             self._late_buckets = parallel.make_buckets(split, bucket)
-        if use_graph and model.training and model._drop_p() > 0:
+        from .head import _use_layers
+        if use_graph and model.training and model._drop_p() > 0 and (model.modality != "both" or _use_layers()):
+            # the fused 'both' head mixes the device-resident step count into its dropout seed; the layer-by-layer
+            # kernels take the seed as a launch argument, which a captured sequence freezes
             raise ValueError("graph replay would repeat the same dropout masks every step; use use_graph=False "
                              "when dropout is active")
 
@@ -97,7 +100,7 @@ class TrainStep:
                 self.grads.of(model.text_model.embedding.weight).zero_()
         run = model._run(audio, input_ids, labels, None, need_grad=True, ws=self.ws,
                          keep=(self.keep[0:1], self.keep[1:2]), norms_ready=self._norms_ready,
-                         grad_scale=1.0 / self.world)
+                         grad_scale=1.0 / self.world, step_state=self.state[0:1])
         if pre_zero:
             run.text.dtable_zeroed = True
         d = run.head.dlogits

@@ -246,3 +246,29 @@ def test_two_ranks_sharing_one_gpu(use_graph, tmp_path):
             continue
         d = float(torch.linalg.vector_norm(pa.detach() - pb))
         assert d < 0.05 * 4e-3 * pa.numel() ** 0.5 + 1e-6, k
+
+
+def test_graph_replay_draws_new_dropout_masks():
+    """With the reference's default dropout the captured step still works: the fused head mixes the device-resident
+    step count into its seed, so consecutive replays drop different units, and forward and backward of one step agree
+    on the mask (a unit is zero in the forward activation exactly where its gradient is zero)."""
+    from mmsa_amd.trainer import TrainStep
+    m = seeded_model("both", vocab=SMALL_VOCAB, dropout0=False).to(DEV).train()
+    m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+    ts = TrainStep(m, use_graph=True)
+    b = batch_tensors(0, 8, vocab=SMALL_VOCAB, device=DEV)
+    zero_sets, losses = [], []
+    for s in range(6):
+        losses.append(float(ts.step(**_step_inputs("both", b))))
+        h1 = ts.ws.buf("head.h1", (8, 128))
+        dln = ts.ws.buf("head.c0.dln", (8, 128))
+        torch.cuda.synchronize()
+        assert torch.equal(h1 == 0, dln == 0)
+        zero_sets.append((h1 == 0).cpu())
+    assert ts._graph is not None and all(np.isfinite(losses))
+    for a, c in zip(zero_sets[3:], zero_sets[4:]):           # replayed steps
+        assert not torch.equal(a, c)
+    dropped = float(zero_sets[-1].float().mean())
+    assert 0.55 < dropped < 0.95                              # relu zeros plus p = 0.5 dropout
+    with pytest.raises(ValueError):
+        TrainStep(seeded_model("audio", dropout0=False).to(DEV).train(), use_graph=True)
