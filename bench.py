@@ -16,6 +16,11 @@ import os
 import sys
 import time
 
+# HIP runtime setting, read when the runtime starts: graph kernel nodes are enqueued as ordinary commands instead of
+# from pre-recorded packets.  With pre-recorded packets a step replayed as a chain of several graphs was seen to run
+# its last kernels on corrupted arguments; the setting costs nothing measurable on this workload.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "multimodal-sentiment-analysis_amd")):
     if p not in sys.path:

@@ -20,14 +20,8 @@ _SIDE_STREAMS = {}
 import os as _os
 FORK_WGRAD = _os.environ.get("MMSA_FORK_WGRAD", "1") != "0"
 FORK_ANY = _os.environ.get("MMSA_FORK", "1") != "0"     # 0: the whole step on one stream (diagnostics)
-# bit 0 / bit 1: launch the conv2 / conv1 data-gradient kernel ahead of the weight-gradient fork that shares its inputs
-BWD_ORDER = int(_os.environ.get("MMSA_BWD_ORDER", "3"))
-# helper streams of the weight-gradient launches: 0 one for all, 1 one per residual block, 2 one per fork
-WGRAD_STREAMS = int(_os.environ.get("MMSA_WGRAD_STREAMS", "0"))
 # 1: a block's first 3x3 convolution and its 1x1 shortcut share one launch (and one BatchNorm coefficient launch)
 FWD_PAIR = _os.environ.get("MMSA_FWD_PAIR", "1") != "0"
-# 1: the weight gradients of conv1 and of the shortcut (both read the block input) share one launch
-WGRAD_PAIR = _os.environ.get("MMSA_WGRAD_PAIR", "1") != "0"
 
 
 def side_stream(device, which: int = 0) -> torch.cuda.Stream:
@@ -174,16 +168,11 @@ def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: 
     return s
 
 
-def _wgrad_stream(block_index: int, second: bool) -> int:
-    if WGRAD_STREAMS == 0:
-        return 0
-    if WGRAD_STREAMS == 1:
-        return 3 + block_index
-    return 3 + 2 * block_index + int(second)
+def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx: bool):
+    """d_out: [B,H/2,W/2,Cout] -> gradient w.r.t. the block input [B,H,W,Cin] (or None).
 
-
-def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx: bool, block_index: int = 0):
-    """d_out: [B,H/2,W/2,Cout] -> gradient w.r.t. the block input [B,H,W,Cin] (or None)."""
+    The three weight gradients (and the squeeze-excite ones) feed nothing but the optimiser: they run on a helper
+    stream from fork points fixed before the data-gradient kernels, which are launched first."""
     B, H, W, Cin, Cout, name = s.B, s.H, s.W, s.Cin, s.Cout, s.name
     W1, W2 = blk.se.fc[0].weight, blk.se.fc[2].weight
     d_c2 = ws.buf(name + ".d_c2", (B, H, W, Cout))
@@ -193,47 +182,34 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
     ops.resblock_bwd_ew(d_out, s.c2, s.sc, s.coeff2, s.coeffs, s.gate, s.hid, s.gap, s.bsum2, W1, W2, d_c2, d_sc,
                         grads.of(bn2.weight), grads.of(bn2.bias), grads.of(bns.weight), grads.of(bns.bias),
                         None, None, scratch, B, H, W, Cout, training)
-    wsz = max(ops.conv_wgrad_workspace(B, H, W, Cout, Cout, 9), ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 9),
-              ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 1))
+    wsz = max(ops.conv_wgrad_workspace(B, H, W, Cout, Cout, 9), ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 9))
     wg = ws.buf(name + ".wgrad_ws", wsz)
-    # The three weight gradients feed nothing but the optimiser: they run on a helper stream while the data
-    # gradient chain (the critical path into the previous block) continues on the main stream.
-    # (the data-gradient kernel is launched first, the fork point having been fixed before it)
-    f2 = fork(ws, d_out.device, _wgrad_stream(block_index, False), enable=FORK_WGRAD).mark()           # d_c2 / d_sc are ready
+    wgs = ws.buf(name + ".wgrad_ws_sc", ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 1))
     d_h1 = ws.buf(name + ".d_h1", (B, H, W, Cout))
-    if BWD_ORDER & 1:
-        ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
-    with f2:
+    d_c1 = d_h1                                   # bn_relu_bwd works in place
+    d_in = ws.buf(name + ".d_in", (B, H, W, Cin)) if need_dx else None
+
+    def wgrad_conv2():                            # needs d_c2 (and the scratch of the elementwise backward)
         ops.resblock_bwd_se_wgrad(scratch, s.hid, s.gap, grads.of(W1), grads.of(W2), B, H, W, Cout)
         ops.conv_wgrad(s.h1, d_c2, grads.of(blk.conv2.weight), wg, B, H, W, Cout, Cout, ops.TAPS3X3)
-        if not WGRAD_PAIR:
-            ops.conv_wgrad(s.a_in, d_sc, grads.of(blk.shortcut[0].weight), wg, B, H, W, Cin, Cout, ops.TAPS1X1)
-    if not BWD_ORDER & 1:
-        ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
+
+    def wgrad_conv1_shortcut():                   # needs d_c1 and d_sc; both read the block input
+        ops.conv_wgrad_pair(s.a_in, d_c1, grads.of(blk.conv1.weight), d_sc, grads.of(blk.shortcut[0].weight), wg, wgs,
+                            B, H, W, Cin, Cout)
+
+    f2 = fork(ws, d_out.device, enable=FORK_WGRAD).mark()           # d_c2 / d_sc are ready
+    ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
+    with f2:
+        wgrad_conv2()
     sc2 = ws.buf(name + ".bnrelu_scratch", ops.bn_relu_bwd_scratch(B * H * W, Cout))
     ops.bn_relu_bwd(d_h1, s.c1, s.coeff1, grads.of(blk.bn1.weight), grads.of(blk.bn1.bias), sc2, B * H * W, Cout,
                     training)
-    d_c1 = d_h1
-    f1 = fork(ws, d_out.device, _wgrad_stream(block_index, True), enable=FORK_WGRAD).mark()           # d_c1 is ready
-    d_in = ws.buf(name + ".d_in", (B, H, W, Cin)) if need_dx else None
-
-    def data_gradient():
+    f1 = fork(ws, d_out.device, enable=FORK_WGRAD).mark()           # d_c1 is ready
+    if need_dx:
         # 3x3 branch and 1x1 shortcut in one launch (one K loop over both operand pairs)
-        if need_dx:
-            ops.conv_fwd_dual(d_c1, s.w1d, d_sc, s.wsd, d_in, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
-    if BWD_ORDER & 2:
-        data_gradient()
-    # (a helper stream of its own needs a slab workspace of its own)
-    wg1 = ws.buf(name + ".wgrad_ws1", wsz) if WGRAD_STREAMS == 2 else wg
+        ops.conv_fwd_dual(d_c1, s.w1d, d_sc, s.wsd, d_in, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
     with f1:
-        if WGRAD_PAIR:
-            wgs = ws.buf(name + ".wgrad_ws_sc", ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 1))
-            ops.conv_wgrad_pair(s.a_in, d_c1, grads.of(blk.conv1.weight), d_sc, grads.of(blk.shortcut[0].weight), wg1,
-                                wgs, B, H, W, Cin, Cout)
-        else:
-            ops.conv_wgrad(s.a_in, d_c1, grads.of(blk.conv1.weight), wg1, B, H, W, Cin, Cout, ops.TAPS3X3)
-    if not BWD_ORDER & 2:
-        data_gradient()
+        wgrad_conv1_shortcut()
     return d_in
 
 
@@ -283,11 +259,10 @@ def audio_backward(m, st, dfeat: torch.Tensor, training: bool, grads: Grads, ws:
     B = st.B
     d = ws.buf("audio.d_last", (B, st.P, st.C))
     ops.gap_bwd(dfeat.contiguous(), d, B, st.P, st.C)
-    for i, (blk, s) in enumerate(zip((m.res_block3, m.res_block2, m.res_block1), reversed(st.blocks))):
-        d = block_backward(blk, s, d, training, grads, ws, need_dx=True, block_index=i)
+    for blk, s in zip((m.res_block3, m.res_block2, m.res_block1), reversed(st.blocks)):
+        d = block_backward(blk, s, d, training, grads, ws, need_dx=True)
     conv0, bn0 = m.conv1[0], m.conv1[1]
     scratch = ws.buf("stem.bwd_scratch", ops.stem_bwd_scratch(B, st.H))
     ops.stem_bwd(st.x, conv0.weight, conv0.bias, st.coeff0, d, grads.of(conv0.weight), grads.of(conv0.bias),
                  grads.of(bn0.weight), grads.of(bn0.bias), scratch, B, st.H, st.W, training)
-    for which in sorted({_wgrad_stream(i, sec) for i in range(3) for sec in (False, True)}):
-        fork(ws, dfeat.device, which).join()     # all weight gradients are in
+    fork(ws, dfeat.device).join()                # all weight gradients are in
