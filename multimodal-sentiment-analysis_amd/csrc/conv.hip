@@ -49,6 +49,9 @@ constexpr int KC = 32;        // channels per K chunk
 #define IGEMM_NBUF_VALUE 5
 #endif
 constexpr int IGEMM_NBUF = IGEMM_NBUF_VALUE;   // LDS buffers of the forward / data-gradient kernel (chunks in flight + 2)
+// The 128 x 32 tile (data gradient into a 32-channel map) takes 20 KiB per buffer: a ring of three lets two workgroups
+// share a CU, which is worth more there than the deeper prefetch (59 -> 55 us on the 32 x 32 x 65 x 64 layer).
+constexpr int igemm_nbuf(int BM, int BN) { return BM == 128 && BN == 32 && IGEMM_NBUF > 3 ? 3 : IGEMM_NBUF; }
 
 struct ConvGeom {
   int B, H, W, Cin, Cout, ntaps;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
   constexpr int B_LD = BN / 32;
   constexpr int LD = A_LD + B_LD;
   constexpr int BUF_FLOATS = (BM + BN) * KC;   // one LDS buffer: A rows then B rows of one 32-channel chunk
-  constexpr int NBUF = IGEMM_NBUF;             // ring of LDS buffers; a chunk is requested NBUF-1 steps ahead
+  constexpr int NBUF = igemm_nbuf(BM, BN);     // ring of LDS buffers; a chunk is requested NBUF-1 steps ahead
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   LAB_STAMP(0);
@@ -464,7 +467,8 @@ __device__ __forceinline__ void conv_wgrad_body(const float* __restrict__ X, con
     const int r0 = (strip - b * strips_per_img) * R;
     __syncthreads();  // the previous strip's reads are done
     // staging in batches of eight independent 16-byte loads per thread, so that one round trip to memory covers
-    // eight pieces instead of one
+    // eight pieces instead of one (requesting both strips whole before writing any of them is faster for the kernel
+    // alone and slower inside the training step, where the larger bursts collide with the concurrent kernels)
     const float* Xb = X + (long)b * g.H * g.W * g.Cin + cin0;
     const int nx = (R + 2) * WP * 8;
     for (int i0 = t; i0 < nx; i0 += 256 * 8) {
@@ -708,7 +712,7 @@ int fill_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout, int ntaps, co
 template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM>
 int launch_igemm_one(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int tiles, dim3 grid,
                      const ConvMulti& multi, hipStream_t s) {
-  constexpr size_t shmem = IGEMM_NBUF * (size_t)(BM + BN) * KC * sizeof(float);
+  constexpr size_t shmem = igemm_nbuf(BM, BN) * (size_t)(BM + BN) * KC * sizeof(float);
   static bool attr_set = false;   // raising the dynamic-LDS limit is sticky per kernel; benign if raced
   if (shmem > 48 * 1024 && !attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM>),
