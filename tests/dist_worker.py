@@ -34,7 +34,7 @@ def main():
     m = seeded_model("both", vocab=SMALL_VOCAB).to("cuda").train()
     m.fusion_layer.draw_modality_dropout = lambda: (False, False)
     ts = TrainStep(m, use_graph=use_graph)
-    assert ts.dist and ts.world == world and ts.overlap
+    assert ts.dist and ts.world == world and ts.overlap == (os.environ.get("MMSA_OVERLAP_ALLREDUCE", "auto") != "0")
     losses = []
     if os.environ.get("MMSA_DIST_DEBUG"):
         import threading
