@@ -10,6 +10,7 @@ import sys
 # two processes time-share one GPU's hardware queues here: with four streams each, cross-stream waits between
 # descheduled queues make progress crawl, so every rank keeps its step on one stream
 os.environ["MMSA_FORK"] = "0"
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", os.environ.get("MMSA_TEST_PACKET_CAPTURE", "0"))
 
 import torch
 import torch.distributed as dist
