@@ -268,7 +268,7 @@ def conv_wgrad_pair(X, dY9, dW9, dY1, dW1, ws9, ws1, B, H, W, Cin, Cout, taps=No
         raise ValueError("conv_wgrad_pair: operand sizes do not match the geometry")
     if ws9.numel() < conv_wgrad_workspace(B, H, W, Cin, Cout, 9) or ws1.numel() < conv_wgrad_workspace(B, H, W, Cin, Cout, 1):
         raise ValueError("conv_wgrad_pair: workspace too small")
-    ev = _prof_begin("conv_wgrad_kernel<9>", 2.0 * n * Cin * Cout * 10)
+    ev = _prof_begin("conv_wgrad_pair_kernel", 2.0 * n * Cin * Cout * 10)
     _lib.call("mmsa_conv_wgrad_pair", _chk(X), _chk(dY9), _chk(dY1), _chk(ws9), _chk(ws1), _chk(dW9), _chk(dW1), B, H, W,
               Cin, Cout, _iarr([t[0] for t in taps]), _iarr([t[1] for t in taps]), _stream())
     if ev is not None:
