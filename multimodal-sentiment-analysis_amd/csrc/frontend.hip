@@ -6,9 +6,9 @@
 //
 // Kernel 1 (logmel_db): one workgroup per (utterance, group of FPB consecutive frames).  The group's
 //   (FPB+1)*512 reflect-padded samples are staged once in LDS (frames overlap by half), each frame is
-//   windowed, packed as a 512-point complex sequence, transformed with a radix-2 Stockham FFT in LDS,
-//   unpacked to the 513 one-sided power bins, multiplied by the (sparse, triangular) mel filterbank
-//   and converted to dB.  Output: dB map, coalesced over frames.
+//   windowed, packed as a 512-point complex sequence, transformed with a radix-8 Stockham FFT (8-point
+//   DFTs in registers, three passes through LDS), unpacked to the 513 one-sided power bins, multiplied
+//   by the (sparse, triangular) mel filterbank and converted to dB.
 // Kernel 2 (logmel_norm): one workgroup per utterance: max -> (max-80) floor -> mean / unbiased std
 //   (two-pass, double accumulators) -> (x-mean)/(std+1e-8) -> clamp -> NaN/Inf scrub, in place.
 #include "mmsa_common.h"
@@ -19,8 +19,30 @@ constexpr int NFFT = 1024;
 constexpr int HOP = 512;
 constexpr int NBINS = 513;
 constexpr int NMEL = 64;
-constexpr int FPB = 2;  // frames per workgroup (short workgroups: the launch is latency-bound at small batches)
+constexpr int FPB = 4;  // frames per workgroup: 64 threads each
 
+// 8-point DFT in registers (outputs in natural order).
+__device__ __forceinline__ void dft8(float2 (&v)[8]) {
+  auto add = [](float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); };
+  auto sub = [](float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); };
+  auto mul_mi = [](float2 a) { return make_float2(a.y, -a.x); };   // times -i
+  const float2 a0 = add(v[0], v[4]), a4 = sub(v[0], v[4]), a2 = add(v[2], v[6]), a6 = mul_mi(sub(v[2], v[6]));
+  const float2 a1 = add(v[1], v[5]), a5 = sub(v[1], v[5]), a3 = add(v[3], v[7]), a7 = mul_mi(sub(v[3], v[7]));
+  const float2 b0 = add(a0, a2), b2 = sub(a0, a2), b4 = add(a4, a6), b6 = sub(a4, a6);
+  const float2 b1 = add(a1, a3), b3 = mul_mi(sub(a1, a3)), b5 = add(a5, a7), b7 = sub(a5, a7);
+  constexpr float h = 0.70710678118654752440f;
+  const float2 w1b5 = make_float2(h * (b5.x + b5.y), h * (b5.y - b5.x));      // e^{-i pi/4} b5
+  const float2 w3b7 = make_float2(h * (b7.y - b7.x), -h * (b7.x + b7.y));     // e^{-3i pi/4} b7
+  v[0] = add(b0, b1); v[4] = sub(b0, b1);
+  v[2] = add(b2, b3); v[6] = sub(b2, b3);
+  v[1] = add(b4, w1b5); v[5] = sub(b4, w1b5);
+  v[3] = add(b6, w3b7); v[7] = sub(b6, w3b7);
+}
+
+// One workgroup = FPB consecutive frames of one utterance, 64 threads per frame.  The 1024 real samples of a frame
+// are windowed and packed as a 512-point complex sequence, transformed by a radix-8 Stockham FFT (three passes with
+// an 8-point DFT in registers: three barriers instead of the nine of a radix-2 transform), unpacked to the 513
+// one-sided power bins, multiplied by the (sparse, triangular) mel filterbank and converted to dB.
 __global__ __launch_bounds__(256) void logmel_db_kernel(
     const float* __restrict__ wave, long wave_stride, int n_valid, int n_target, int n_frames,
     const float* __restrict__ window,   // [1024]
@@ -31,17 +53,47 @@ __global__ __launch_bounds__(256) void logmel_db_kernel(
     float* __restrict__ out)            // [B][64][n_frames] dB
 {
   __shared__ float seg[(FPB + 1) * HOP];
-  __shared__ float2 fa[512];
-  __shared__ float2 fb[512];
-  __shared__ float power[NBINS + 3];
+  // the two FFT buffers are padded (one element per 8 in fa's first use, 8 per 64 in fb) so that the strided stores
+  // of the first two passes spread over the LDS banks; the power spectrum reuses fb once the transform is done
+  __shared__ float2 fa[FPB][576];
+  __shared__ float2 fb[FPB][576];
   __shared__ float dbv[NMEL][FPB + 1];
-  __shared__ float2 tws[256];   // stage twiddles: read once instead of once per butterfly stage
+  float (*power)[NBINS + 3] = reinterpret_cast<float (*)[NBINS + 3]>(&fb[0][0]);
+  static_assert(sizeof(float) * FPB * (NBINS + 3) <= sizeof(float2) * FPB * 576, "power must fit in fb");
+  __shared__ float2 tws[512];   // e^{-2 pi i m / 512}
 
   const int t = threadIdx.x;
-  tws[t] = make_float2(tw512[2 * t], tw512[2 * t + 1]);
+  {
+    const float2 w = make_float2(tw512[2 * t], tw512[2 * t + 1]);
+    tws[t] = w;
+    tws[t + 256] = make_float2(-w.x, -w.y);
+  }
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * FPB;
   const float* w = wave + (long)b * wave_stride;
+  const int fi = t >> 6, j = t & 63;
+
+  // Constants this thread will need later are requested now, so that their memory latency passes behind the staging
+  // and the transform: its window pair per packed sample, the unpack twiddles of its bins, its mel weights.
+  constexpr int UNP = (FPB * NBINS + 255) / 256;   // unpack items per thread
+  constexpr int MW = 16;                           // mel weights held in registers per lane (rest: read on demand)
+  float2 wv[8], utw[UNP];
+  float mwt[MW];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) wv[r] = *reinterpret_cast<const float2*>(window + 2 * (j + 64 * r));
+#pragma unroll
+  for (int u = 0; u < UNP; ++u) {
+    const int i = t + 256 * u;
+    const int k = i < FPB * NBINS ? i % NBINS : 0;
+    utw[u] = *reinterpret_cast<const float2*>(tw1024 + 2 * k);
+  }
+  const int mel_m = t >> 2, mel_q = t & 3;
+  const int mel_lo = melrange[2 * mel_m], mel_hi = melrange[2 * mel_m + 1];
+#pragma unroll
+  for (int u = 0; u < MW; ++u) {
+    const int bin = min(mel_lo + mel_q + 4 * u, NBINS - 1);
+    mwt[u] = melfb[bin * NMEL + mel_m];
+  }
 
   // stage reflect-padded samples: padded index q = f0*512 + i  <->  sample n = q - 512
   for (int i = t; i < (FPB + 1) * HOP; i += 256) {
@@ -54,64 +106,97 @@ __global__ __launch_bounds__(256) void logmel_db_kernel(
   }
   __syncthreads();
 
-  for (int fi = 0; fi < FPB; ++fi) {
-    if (f0 + fi >= n_frames) break;  // uniform
-    // window + pack even/odd samples into a 512-point complex sequence
-    {
-      const float* s = seg + fi * HOP;
+  float2 v[8];
+  // pass 1 (sub-transform length 1): inputs straight from the windowed samples, z[n] = (x[2n], x[2n+1]) * window
+  {
+    const float* sgm = seg + fi * HOP;
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const int n = t + r * 256;
-        fa[n] = make_float2(s[2 * n] * window[2 * n], s[2 * n + 1] * window[2 * n + 1]);
+    for (int r = 0; r < 8; ++r) {
+      const int n = j + 64 * r;
+      v[r] = make_float2(sgm[2 * n] * wv[r].x, sgm[2 * n + 1] * wv[r].y);
+    }
+    dft8(v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) fa[fi][j * 9 + r] = v[r];   // element i lives at i + i / 8
+  }
+  __syncthreads();
+  // pass 2 (sub-transform length 8)
+  {
+    const int k = j & 7;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float2 x = fa[fi][j + (j >> 3) + 72 * r];
+      const float2 tw = tws[r * k * 8];
+      v[r] = make_float2(x.x * tw.x - x.y * tw.y, x.x * tw.y + x.y * tw.x);
+    }
+    dft8(v);
+    const int j0 = (j >> 3) * 72 + k;                         // element i lives at i + 8 * (i / 64)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) fb[fi][j0 + 8 * r] = v[r];
+  }
+  __syncthreads();
+  // pass 3 (sub-transform length 64)
+  {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float2 x = fb[fi][j + 72 * r];
+      const float2 tw = tws[r * j];
+      v[r] = make_float2(x.x * tw.x - x.y * tw.y, x.x * tw.y + x.y * tw.x);
+    }
+    dft8(v);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) fa[fi][j + 64 * r] = v[r];
+  }
+  __syncthreads();
+  // unpack the real-input spectrum: X[k] = (Z[k]+conj(Z[512-k]))/2 + W^k (Z[k]-conj(Z[512-k]))/(2i)
+#pragma unroll
+  for (int u = 0; u < UNP; ++u) {
+    const int i = t + 256 * u;
+    if (i >= FPB * NBINS) break;
+    const int f = i / NBINS, k = i - f * NBINS;
+    const float2 zk = fa[f][k & 511];
+    const float2 zc = fa[f][(512 - k) & 511];
+    const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);   // even part
+    const float dr = 0.5f * (zk.x - zc.x), di = 0.5f * (zk.y + zc.y);   // (Z - conj Z')/2
+    // odd part = (dr + i di) / i = di - i dr
+    const float orr = di, oi = -dr;
+    const float c = utw[u].x, sn = utw[u].y;
+    const float xr = er + (orr * c - oi * sn);
+    const float xi = ei + (orr * sn + oi * c);
+    power[f][k] = xr * xr + xi * xi;
+  }
+  __syncthreads();
+  // mel: 4 lanes per filter; each filter weight is fetched once and applied to all frames of the group, then dB
+  {
+    const int m = mel_m, q = mel_q;
+    float acc[FPB];
+#pragma unroll
+    for (int f = 0; f < FPB; ++f) acc[f] = 0.f;
+#pragma unroll
+    for (int u = 0; u < MW; ++u) {
+      const int bin = mel_lo + q + 4 * u;
+      if (bin < mel_hi) {
+#pragma unroll
+        for (int f = 0; f < FPB; ++f) acc[f] = fmaf(mwt[u], power[f][bin], acc[f]);
       }
     }
-    float2* x = fa;
-    float2* y = fb;
-#pragma unroll 1
-    for (int p = 1; p < 512; p <<= 1) {
-      __syncthreads();
-      const int k = t & (p - 1);
-      const int j = ((t - k) << 1) + k;
-      const int ti = k * (256 / p);
-      const float c = tws[ti].x, sn = tws[ti].y;
-      const float2 u0 = x[t];
-      const float2 v = x[t + 256];
-      const float2 u1 = make_float2(v.x * c - v.y * sn, v.x * sn + v.y * c);
-      y[j] = make_float2(u0.x + u1.x, u0.y + u1.y);
-      y[j + p] = make_float2(u0.x - u1.x, u0.y - u1.y);
-      float2* tmp = x; x = y; y = tmp;
+    for (int bin = mel_lo + q + 4 * MW; bin < mel_hi; bin += 4) {   // filters wider than 4 * MW bins
+      const float wgt = melfb[bin * NMEL + m];
+#pragma unroll
+      for (int f = 0; f < FPB; ++f) acc[f] = fmaf(wgt, power[f][bin], acc[f]);
     }
-    __syncthreads();
-    // unpack the real-input spectrum: X[k] = (Z[k]+conj(Z[512-k]))/2 + W^k (Z[k]-conj(Z[512-k]))/(2i)
-    for (int k = t; k <= 512; k += 256) {
-      const float2 zk = x[k & 511];
-      const float2 zc = x[(512 - k) & 511];
-      const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);   // even part
-      const float dr = 0.5f * (zk.x - zc.x), di = 0.5f * (zk.y + zc.y);   // (Z - conj Z')/2
-      // odd part = (dr + i di) / i = di - i dr
-      const float orr = di, oi = -dr;
-      const float c = tw1024[2 * k], sn = tw1024[2 * k + 1];
-      const float xr = er + (orr * c - oi * sn);
-      const float xi = ei + (orr * sn + oi * c);
-      power[k] = xr * xr + xi * xi;
+#pragma unroll
+    for (int f = 0; f < FPB; ++f) {
+      float a = acc[f];
+      a += __shfl_xor(a, 1, 64);
+      a += __shfl_xor(a, 2, 64);
+      if (q == 0) dbv[m][f] = 10.0f * log10f(fmaxf(a, 1e-10f));
     }
-    __syncthreads();
-    // mel: 4 lanes per filter, then dB
-    {
-      const int m = t >> 2, q = t & 3;
-      const int lo = melrange[2 * m], hi = melrange[2 * m + 1];
-      float acc = 0.f;
-      for (int f = lo + q; f < hi; f += 4) acc = fmaf(melfb[f * NMEL + m], power[f], acc);
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      if (q == 0) dbv[m][fi] = 10.0f * log10f(fmaxf(acc, 1e-10f));
-    }
-    // the next frame's first barrier orders power[] / fa[] reuse
   }
   __syncthreads();
   for (int i = t; i < NMEL * FPB; i += 256) {
-    const int m = i / FPB, fi = i - m * FPB;
-    if (f0 + fi < n_frames) out[((long)b * NMEL + m) * n_frames + f0 + fi] = dbv[m][fi];
+    const int m = i / FPB, f = i - m * FPB;
+    if (f0 + f < n_frames) out[((long)b * NMEL + m) * n_frames + f0 + f] = dbv[m][f];
   }
 }
 
