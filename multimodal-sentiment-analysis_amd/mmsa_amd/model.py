@@ -364,13 +364,12 @@ class MultimodalSentimentModel(nn.Module):
         run = SimpleNamespace(audio=None, text=None, l2=False, touched=set())
         a_feat = t_feat = None
         if self.modality == "both":
-            # the two branches are independent until the head: the (small) text branch runs on a helper stream
-            # (the audio chain is enqueued first: see the note on launch order in _backward)
-            f = audio_engine.fork(ws, arena.device, 1).mark()
+            # the two branches are independent until the head: the (small) text branch runs on a helper stream; it is
+            # enqueued first so that it starts beside the stem instead of colliding with the last block's convolutions
+            with audio_engine.fork(ws, arena.device, 1) as f:
+                t_feat, run.text = text_engine.text_forward(self.text_model, input_ids, need_grad, ws)
             a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, self.audio_model.training,
                                                            need_grad, ws)
-            with f:
-                t_feat, run.text = text_engine.text_forward(self.text_model, input_ids, need_grad, ws)
             f.join()
         elif self.modality == "audio":
             a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, self.audio_model.training,
