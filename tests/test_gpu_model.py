@@ -184,3 +184,23 @@ def test_fused_head_equals_layer_by_layer_head(monkeypatch, drop):
             continue
         scale = float(g1[k].abs().max()) + 1e-8
         assert float((g0[k] - g1[k]).abs().max()) <= 2e-4 * scale + 1e-7, k
+
+
+@pytest.mark.parametrize("B", [1, 5, 33])
+def test_eval_forward_odd_batch_sizes_and_padding_rows(B):
+    """Batch sizes that are not multiples of anything the kernels tile by, a row of nothing but padding tokens and a
+    row of maximal length: logits vs the oracle (1e-4 relative), identical argmax."""
+    from oracle import model_ref
+    m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).eval()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    b = batch_tensors(7, B, vocab=SMALL_VOCAB)
+    ids = b["input_ids"].clone()
+    ids[0] = 0                                            # all padding
+    if B > 1:
+        ids[-1] = torch.randint(1, SMALL_VOCAB, (ids.shape[1],), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        got = m(audio=b["audio"].to(DEV), input_ids=ids.to(DEV), labels=b["label"].to(DEV))
+        ref = model_ref.forward(sd, "both", b["audio"], ids, b["label"])
+    close(got["logits"], ref["logits"].numpy())
+    assert torch.equal(got["logits"].argmax(1).cpu(), ref["logits"].argmax(1))
+    assert abs(float(got["loss"]) - float(ref["loss"])) < 1e-4

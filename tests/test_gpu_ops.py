@@ -317,3 +317,18 @@ def test_paired_weight_gradients_equal_separate_launches(B, H, W, Cin, Cout):
     ws1.fill_(3.0)
     ops.conv_wgrad_pair(X, dY9, b9, dY1, b1, ws9, ws1, B, H, W, Cin, Cout)
     assert torch.equal(a9, b9) and torch.equal(a1, b1)
+
+
+def test_front_end_and_resampler_on_very_short_input():
+    """Inputs shorter than one FFT frame / than the resampling filter: everything past them is zero padding."""
+    from mmsa_amd.frontend import LogMelFrontEnd, Resampler
+    from oracle import frontend_ref, resample_ref
+    g = torch.Generator().manual_seed(9)
+    tiny = torch.randn(2, 100, generator=g) * 0.1
+    fe = LogMelFrontEnd(DEV)
+    check(fe(tiny.to(DEV)).cpu(), torch.from_numpy(frontend_ref.logmel_f64(tiny.numpy())), 1e-4)
+    pcm = torch.randn(1, 1, 10, generator=g) * 0.1
+    got = Resampler(16000, 22050, DEV)(pcm.to(DEV)).cpu()
+    ref = resample_ref.prepare(pcm[0].numpy(), 16000, dtype=np.float64)
+    check(got, torch.from_numpy(ref[None]), 2e-6)
+    assert torch.equal(got[:, 14:], torch.zeros(1, 66150 - 14))          # ceil(441 * 10 / 320) = 14 samples
