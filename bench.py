@@ -96,6 +96,7 @@ def main():
     torch.manual_seed(42)
     # the training driver's defaults (multimodal_train.py:71-76,457-468): dropout 0.5 / 0.3 / 0.6, modality dropout 0.3
     model = MultimodalSentimentModel("both", audio_dropout=0.5, text_dropout=0.3, fusion_dropout=0.6).to(dev).train()
+    torch.manual_seed(42 + rank)     # identical replicas, per-rank stream for the modality-dropout draws (rank 0 = 42)
     fe = LogMelFrontEnd(dev)
     use_graph = not args.no_graph
     ts = TrainStep(model, lr=1e-3, weight_decay=1e-4, max_norm=1.0, frontend=fe, use_graph=use_graph)
@@ -136,7 +137,9 @@ def main():
     if rank == 0 and args.profile_steps > 0:
         # per-kernel timing of the dense contractions with HIP events on the launch stream (instrumented eager steps)
         ops.PROFILE = {}
-        ts_prof = ts if not use_graph else TrainStep(model, frontend=fe, use_graph=False)
+        # (a local step object: only this rank runs the instrumented steps, so they must not enter collectives)
+        ts_prof = ts if (not use_graph and not distributed) else TrainStep(model, frontend=fe, use_graph=False,
+                                                                            distributed=False)
         for i in range(args.profile_steps):
             b = batches[i % N_DISTINCT_BATCHES]
             ts_prof.step(wave=b["wave"], input_ids=b["input_ids"], labels=b["label"])

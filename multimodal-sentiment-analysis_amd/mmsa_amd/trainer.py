@@ -31,7 +31,7 @@ from .workspace import Grads, Workspace
 class TrainStep:
     def __init__(self, model: MultimodalSentimentModel, lr: float = 1e-3, weight_decay: float = 1e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: Optional[float] = 1.0, frontend=None,
-                 use_graph: bool = False, process_group=None, bucket_mb: float = 64.0):
+                 use_graph: bool = False, process_group=None, bucket_mb: float = 64.0, distributed: bool = True):
         self.model = model
         self.arena = model._ensure_arena()
         dev = self.arena.device
@@ -57,7 +57,8 @@ class TrainStep:
         self.pg = process_group
         # the collective path is taken whenever a process group exists (also with a single rank, which keeps the
         # multi-rank code path testable on one GPU)
-        self.dist = torch.distributed.is_available() and torch.distributed.is_initialized()
+        # (distributed=False keeps a step local even inside an initialised job: e.g. instrumented steps on one rank)
+        self.dist = distributed and torch.distributed.is_available() and torch.distributed.is_initialized()
         if self.dist:
             self.world = torch.distributed.get_world_size(process_group)
         bucket = int(bucket_mb * 1024 * 1024 / 4)
