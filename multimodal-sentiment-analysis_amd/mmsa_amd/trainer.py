@@ -28,6 +28,11 @@ from .model import L2_LAMBDA, MultimodalSentimentModel
 from .workspace import Grads, Workspace
 
 
+# Only the capturing thread's calls are policed during capture: a process group's watchdog thread (or any other
+# library thread) may touch the runtime meanwhile without invalidating the capture.
+CAPTURE_MODE = "thread_local"
+
+
 class TrainStep:
     def __init__(self, model: MultimodalSentimentModel, lr: float = 1e-3, weight_decay: float = 1e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: Optional[float] = 1.0, frontend=None,
@@ -225,24 +230,24 @@ class TrainStep:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             if not self.dist:
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                     self._body(*args)
                 self._graph = (g, None, None)
             elif self.overlap:
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                     l2 = self._forward_backward(*args, phase="early")
                 gl = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gl, pool=g.pool()):
+                with torch.cuda.graph(gl, pool=g.pool(), capture_error_mode=CAPTURE_MODE):
                     self._forward_backward(*args, phase="late")
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=g.pool()):
+                with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode=CAPTURE_MODE):
                     self._update(l2)
                 self._graph = (g, gl, g2)
             else:
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
                     l2 = self._forward_backward(*args)
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, pool=g.pool()):
+                with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode=CAPTURE_MODE):
                     self._update(l2)
                 self._graph = (g, None, g2)
             # capture only records: the replays below execute this step
