@@ -139,10 +139,11 @@ class AudioTransform:
     Waveform augmentations follow preprocess.py:56-90 with the same ``random`` draw order.
     """
 
-    def __init__(self, augment=False, device="cuda", waveform_only=False):
+    def __init__(self, augment=False, device="cuda", waveform_only=False, strict=False):
         self.augment = augment
         self.device = device
         self.waveform_only = waveform_only
+        self.strict = strict          # True: errors propagate; False: the reference's contract (log, return zeros)
         self._fe = None
         self._rs = {}
 
@@ -270,6 +271,23 @@ class AudioTransform:
         return audio
 
     def __call__(self, audio, sr=SAMPLE_RATE):
+        """``transform(audio[C, T], sr) -> [1, 64, 130]``.  Like the reference (preprocess.py:172-174) a failing
+        utterance is logged and answered with an all-zero map -- except for a missing / broken HIP library
+        (:class:`MmsaError`), which always propagates, and unless ``strict=True``."""
+        try:
+            return self._transform(audio, sr)
+        except _lib.MmsaError:
+            raise
+        except Exception as e:
+            if self.strict:
+                raise
+            import logging
+            logging.getLogger(__name__).error(f"Error in audio transformation: {e}")
+            if self.waveform_only:
+                return torch.zeros((1, TARGET_LENGTH))
+            return torch.zeros((1, N_MELS, N_FRAMES))
+
+    def _transform(self, audio, sr):
         if self.augment and not self.waveform_only:
             # mono mix / resampling as below, then every augmentation on the GPU (waveform ones in one launch, the
             # spectral masks inside the mel stage, ahead of the normalisation: preprocess.py:137-140,162-165)

@@ -332,3 +332,13 @@ def test_front_end_and_resampler_on_very_short_input():
     ref = resample_ref.prepare(pcm[0].numpy(), 16000, dtype=np.float64)
     check(got, torch.from_numpy(ref[None]), 2e-6)
     assert torch.equal(got[:, 14:], torch.zeros(1, 66150 - 14))          # ceil(441 * 10 / 320) = 14 samples
+
+
+def test_audio_transform_error_contract():
+    """preprocess.py:172-174: a failing utterance yields an all-zero map; strict=True re-raises."""
+    from mmsa_amd.frontend import AudioTransform
+    bad = torch.zeros(2, 3, 100)                      # not [C, T]
+    out = AudioTransform(device=DEV)(bad)
+    assert out.shape == (1, 64, 130) and not out.any()
+    with pytest.raises(Exception):
+        AudioTransform(device=DEV, strict=True)(bad)
