@@ -66,6 +66,23 @@ MMSA_API int mmsa_resample_filters_host(int orig_freq, int new_freq, int lowpass
                                         float* kernT, int* orig_out, int* new_out, int* width_out, int* K_out);
 MMSA_API int mmsa_resample_fwd(const float* pcm, int channels, long T, long stride_b, const float* kernT, int orig,
                                int nw, int width, int K, float* out, int n_out, int batch, void* stream);
+/* Noise reduction ahead of the pad / trim: replaces the per-utterance `nr.reduce_noise(y=audio_np, sr=SAMPLE_RATE)` of
+ * preprocess.py:142-148 (package defaults: non-stationary spectral gating, n_fft 1024, hop 256, chunk padding 30 000)
+ * for a batch of equally long rows.  mmsa_denoise_plan (host only) returns, for one chunk of L output samples with
+ * `pad` samples of context per side, the STFT frame count, the first frame and the number of frames that reach the
+ * output, and the scratch need in floats per utterance.  mmsa_denoise_fwd denoises samples [c0, c0+L) of every row of
+ * wave [batch][T] (row stride `stride`) into out[b][c0 .. c0+L) (row stride out_stride); the samples of the row up to
+ * pad before and after the chunk are its context, zeros beyond the row.  window / tw512 / tw1024: the tables of
+ * mmsa_logmel_tables_host.  vt [nt], vf [nf]: normalised time / frequency taps of the mask-smoothing filter (odd
+ * counts, at most 33 / 65).  b_iir: coefficient of the one-pole time-smoothing filter; thresh, slope: sigmoid gate
+ * parameters; prop: share of the mask applied.  ws: batch * ws_floats floats, 16-byte aligned.  lens: null, or [batch]
+ * valid lengths (1..T) when the rows hold utterances of different lengths (then c0 = 0, L = T): each row is gated as
+ * a signal of its own length and its output is zero behind it. */
+MMSA_API int mmsa_denoise_plan(long L, int pad, int* nseg, int* f_lo, int* nfr, long* ws_floats);
+MMSA_API int mmsa_denoise_fwd(const float* wave, long stride, long T, long c0, long L, int pad, int batch,
+                              const int* lens, const float* window, const float* tw512, const float* tw1024,
+                              const float* vt, int nt, const float* vf, int nf, double b_iir, float thresh,
+                              float slope, float prop, float* ws, float* out, long out_stride, void* stream);
 
 
 /* ---- convolutions as implicit GEMM on fp32 MFMA: multimodal_model.py:48-59,64-68 (ResidualBlock convs and 1x1

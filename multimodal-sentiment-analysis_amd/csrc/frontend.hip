@@ -12,6 +12,7 @@
 // Kernel 2 (logmel_norm): one workgroup per utterance: max -> (max-80) floor -> mean / unbiased std
 //   (two-pass, double accumulators) -> (x-mean)/(std+1e-8) -> clamp -> NaN/Inf scrub, in place.
 #include "mmsa_common.h"
+#include "fft512.h"
 
 namespace {
 
@@ -20,24 +21,6 @@ constexpr int HOP = 512;
 constexpr int NBINS = 513;
 constexpr int NMEL = 64;
 constexpr int FPB = 4;  // frames per workgroup: 64 threads each
-
-// 8-point DFT in registers (outputs in natural order).
-__device__ __forceinline__ void dft8(float2 (&v)[8]) {
-  auto add = [](float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); };
-  auto sub = [](float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); };
-  auto mul_mi = [](float2 a) { return make_float2(a.y, -a.x); };   // times -i
-  const float2 a0 = add(v[0], v[4]), a4 = sub(v[0], v[4]), a2 = add(v[2], v[6]), a6 = mul_mi(sub(v[2], v[6]));
-  const float2 a1 = add(v[1], v[5]), a5 = sub(v[1], v[5]), a3 = add(v[3], v[7]), a7 = mul_mi(sub(v[3], v[7]));
-  const float2 b0 = add(a0, a2), b2 = sub(a0, a2), b4 = add(a4, a6), b6 = sub(a4, a6);
-  const float2 b1 = add(a1, a3), b3 = mul_mi(sub(a1, a3)), b5 = add(a5, a7), b7 = sub(a5, a7);
-  constexpr float h = 0.70710678118654752440f;
-  const float2 w1b5 = make_float2(h * (b5.x + b5.y), h * (b5.y - b5.x));      // e^{-i pi/4} b5
-  const float2 w3b7 = make_float2(h * (b7.y - b7.x), -h * (b7.x + b7.y));     // e^{-3i pi/4} b7
-  v[0] = add(b0, b1); v[4] = sub(b0, b1);
-  v[2] = add(b2, b3); v[6] = sub(b2, b3);
-  v[1] = add(b4, w1b5); v[5] = sub(b4, w1b5);
-  v[3] = add(b6, w3b7); v[7] = sub(b6, w3b7);
-}
 
 // One workgroup = FPB consecutive frames of one utterance, 64 threads per frame.  The 1024 real samples of a frame
 // are windowed and packed as a 512-point complex sequence, transformed by a radix-8 Stockham FFT (three passes with

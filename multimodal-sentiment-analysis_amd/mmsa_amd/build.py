@@ -10,7 +10,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(PKG_DIR), "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmmsa_hip.so")
 OBJ_DIR = os.path.join(CSRC, "build")
-SOURCES = ("frontend.hip", "conv.hip", "audio_ew.hip", "text.hip", "dense.hip", "head.hip", "optim.hip")
+SOURCES = ("frontend.hip", "denoise.hip", "conv.hip", "audio_ew.hip", "text.hip", "dense.hip", "head.hip", "optim.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall",
          "-Wno-unused-function"]
 
@@ -32,14 +32,14 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
-    header = os.path.join(CSRC, "mmsa_common.h")
+    headers = (os.path.join(CSRC, "mmsa_common.h"), os.path.join(CSRC, "fft512.h"))
     jobs = []
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, (s, header)):
+        if force or _stale(o, (s, *headers)):
             jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])
 
     def run(cmd):

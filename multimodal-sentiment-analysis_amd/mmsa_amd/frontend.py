@@ -6,8 +6,9 @@ batched HIP call: :class:`LogMelFrontEnd` maps ``[B, n]`` waveforms to ``[B, 1, 
 :class:`AudioTransform` keeps the reference's per-utterance call signature on top of it.
 
 Input at another sample rate goes through :class:`Resampler` first (`preprocess.py:131-134`: torchaudio's sinc
-resampler, one HIP launch per batch, fused with the mono mix and the pad / trim).  Not covered: the spectral-gating
-noise reduction of `preprocess.py:142-148` (the `noisereduce` package is absent from this image).
+resampler, one HIP launch per batch, fused with the mono mix and the pad / trim).  :class:`NoiseReducer` is the
+spectral-gating noise reduction of `preprocess.py:142-148` (the default algorithm of the `noisereduce` package, which
+the reference does not pin and this image does not hold: restated from the package's published description).
 """
 from __future__ import annotations
 
@@ -130,28 +131,73 @@ class Resampler:
         return ops.resample(pcm, self.filters, out)
 
 
+class NoiseReducer:
+    """``nr(wave[B, T], lens=None) -> [B, T]`` on ``device``: the non-stationary spectral gate that
+    ``noisereduce.reduce_noise(y, sr)`` applies with its defaults (preprocess.py:142-148) -- STFT (n_fft 1024, hop 256),
+    magnitude smoothed along time with a 2 s time constant, sigmoid gate two smoothed magnitudes above it, mask smoothed
+    over 500 Hz x 50 ms, inverse STFT -- for a whole batch in four launches.  ``lens`` [B]: valid lengths of rows
+    holding utterances of different lengths; each is gated as a signal of its own length."""
+
+    def __init__(self, sr: int = SAMPLE_RATE, device="cuda", tables=None):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.MmsaError("NoiseReducer runs on an MI355X only; there is no CPU path")
+        _lib.load()
+        self.tables = tables if tables is not None else _tables(self.device)
+        self.filters = ops.denoise_filters(int(sr), self.device)
+
+    def __call__(self, wave: torch.Tensor, lens=None, out: torch.Tensor = None) -> torch.Tensor:
+        if wave.dim() == 1:
+            wave = wave.unsqueeze(0)
+        if wave.dim() != 2:
+            raise ValueError("wave must be [B, n_samples]")
+        wave = wave.to(device=self.device, dtype=torch.float32)
+        if wave.stride(1) != 1:
+            wave = wave.contiguous()
+        if lens is not None:
+            lens = torch.as_tensor(lens, dtype=torch.int32).to(self.device).contiguous()
+        return ops.denoise(wave, self.filters, self.tables, out=out, lens=lens)
+
+
 class AudioTransform:
     """Per-utterance interface of the reference (``transform(audio[C, T], sr) -> [1, 64, 130]`` CPU tensor).
 
     The spectrogram is computed by the HIP front end, so call it from the process that owns the GPU
     (``DataLoader(num_workers=0)``), or use ``waveform_only=True`` in worker processes -- they then return the
     prepared ``[1, 66150]`` waveform and the training process runs :class:`LogMelFrontEnd` on whole batches.
-    Waveform augmentations follow preprocess.py:56-90 with the same ``random`` draw order.
+    Waveform augmentations follow preprocess.py:56-90 with the same ``random`` draw order.  ``noise_reduce`` (on, as
+    in the reference, `:142-148`) runs :class:`NoiseReducer` between the augmentations and the pad / trim; it needs the
+    GPU, so worker processes that must not touch it pass ``noise_reduce=False`` and leave that step to the training
+    process.
     """
 
-    def __init__(self, augment=False, device="cuda", waveform_only=False, strict=False):
+    def __init__(self, augment=False, device="cuda", waveform_only=False, strict=False, noise_reduce=True):
         self.augment = augment
         self.device = device
         self.waveform_only = waveform_only
         self.strict = strict          # True: errors propagate; False: the reference's contract (log, return zeros)
+        self.noise_reduce = noise_reduce
         self._fe = None
+        self._nr = None
         self._rs = {}
 
     def __getstate__(self):
         d = dict(self.__dict__)
         d["_fe"] = None            # device tables are rebuilt lazily in the receiving process
+        d["_nr"] = None
         d["_rs"] = {}
         return d
+
+    def _front_end(self):
+        if self._fe is None:
+            self._fe = LogMelFrontEnd(self.device)
+        return self._fe
+
+    def _reducer(self):
+        if self._nr is None:
+            fe = self._front_end()
+            self._nr = NoiseReducer(SAMPLE_RATE, fe.device, fe.tables)
+        return self._nr
 
     # -- augmentations (host side, training only) ------------------------------------------------
     def time_shift(self, audio, shift_limit=0.1):
@@ -226,9 +272,8 @@ class AudioTransform:
         """``waves [B, n]`` (mono, 22 050 Hz, un-padded) -> ``[B, 1, 64, 130]`` on the GPU: the reference's
         augmented training transform for a whole batch in two launches (waveform augmentation + pad/trim, then the
         mel stage with the spectral masks).  ``rows`` / ``masks`` default to fresh draws, utterance by utterance."""
-        if self._fe is None:
-            self._fe = LogMelFrontEnd(self.device)
-        dev = self._fe.device
+        fe = self._front_end()
+        dev = fe.device
         waves = waves.to(device=dev, dtype=torch.float32)
         if waves.stride(1) != 1:
             waves = waves.contiguous()
@@ -240,22 +285,33 @@ class AudioTransform:
             # the reference consumes torch's generator for the noise (randn_like); so does the seed of ours
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         params = torch.tensor(rows, dtype=torch.float64).reshape(B, 4).to(dev)
-        out = torch.empty((B, TARGET_LENGTH), dtype=torch.float32, device=dev)
-        ops.augment_wave(waves, params, out, 0.005, seed)
+        if self.noise_reduce:
+            # the gate sees each utterance at its augmented length, before the pad / trim (preprocess.py:137-156)
+            lens = [n if r[3] <= 0 else int(math.ceil(n / r[3])) for r in rows]
+            aug = torch.empty((B, max(lens)), dtype=torch.float32, device=dev)
+            ops.augment_wave(waves, params, aug, 0.005, seed)
+            aug = self._reducer()(aug, lens=lens)
+            out = torch.zeros((B, TARGET_LENGTH), dtype=torch.float32, device=dev)
+            m = min(aug.shape[1], TARGET_LENGTH)
+            out[:, :m] = aug[:, :m]
+        else:
+            out = torch.empty((B, TARGET_LENGTH), dtype=torch.float32, device=dev)
+            ops.augment_wave(waves, params, out, 0.005, seed)
         if return_wave:
             return out
         mk = None if masks is None else torch.tensor(masks, dtype=torch.int32).reshape(B, 4)
-        return self._fe(out, specmask=mk)
+        return fe(out, specmask=mk)
 
     def prepare_waveform(self, audio: torch.Tensor, sr: int = SAMPLE_RATE) -> torch.Tensor:
-        """Everything before the mel stage that this build covers: mono mix, resampling, augmentation, pad/trim."""
+        """Everything before the mel stage: mono mix, resampling, augmentation, noise reduction, pad/trim."""
         if audio.dim() == 1:
             audio = audio.unsqueeze(0)
         if sr != SAMPLE_RATE:
             # preprocess.py:127-134: mono mix and resampling in one HIP launch (needs the process that owns the GPU)
             if sr not in self._rs:
                 self._rs[sr] = Resampler(sr, SAMPLE_RATE, self.device)
-            n_out = None if self.augment else TARGET_LENGTH   # augmentations see the full resampled length
+            # augmentations and the noise gate see the full resampled length
+            n_out = None if (self.augment or self.noise_reduce) else TARGET_LENGTH
             audio = self._rs[sr](audio, n_out=n_out).cpu()
         elif audio.shape[0] > 1:
             audio = audio.mean(dim=0, keepdim=True)
@@ -263,6 +319,8 @@ class AudioTransform:
             audio = self.time_shift(audio)
             audio = self.add_noise(audio)
             audio = self.pitch_shift(audio, SAMPLE_RATE)
+        if self.noise_reduce and audio.shape[1] > 0:
+            audio = self._reducer()(audio).cpu()
         n = audio.shape[1]
         if n < TARGET_LENGTH:
             audio = torch.nn.functional.pad(audio, (0, TARGET_LENGTH - n))
@@ -288,24 +346,24 @@ class AudioTransform:
             return torch.zeros((1, N_MELS, N_FRAMES))
 
     def _transform(self, audio, sr):
-        if self.augment and not self.waveform_only:
-            # mono mix / resampling as below, then every augmentation on the GPU (waveform ones in one launch, the
-            # spectral masks inside the mel stage, ahead of the normalisation: preprocess.py:137-140,162-165)
-            if audio.dim() == 1:
-                audio = audio.unsqueeze(0)
-            if sr != SAMPLE_RATE:
-                if sr not in self._rs:
-                    self._rs[sr] = Resampler(sr, SAMPLE_RATE, self.device)
-                audio = self._rs[sr](audio, n_out=None)
-            elif audio.shape[0] > 1:
-                audio = audio.mean(dim=0, keepdim=True)
-            return self.augment_batch(audio)[0].cpu()
-        wave = self.prepare_waveform(audio, sr)
         if self.waveform_only:
-            return wave
-        if self._fe is None:
-            self._fe = LogMelFrontEnd(self.device)
-        return self._fe(wave)[0].cpu()
+            return self.prepare_waveform(audio, sr)
+        # mono mix / resampling, every augmentation (waveform ones in one launch, the spectral masks inside the mel
+        # stage ahead of the normalisation: preprocess.py:137-140,162-165), the noise gate and the mel stage on the GPU
+        if audio.dim() == 1:
+            audio = audio.unsqueeze(0)
+        if sr != SAMPLE_RATE:
+            if sr not in self._rs:
+                self._rs[sr] = Resampler(sr, SAMPLE_RATE, self.device)
+            full = self.augment or self.noise_reduce       # both see the whole resampled utterance
+            audio = self._rs[sr](audio, n_out=None if full else TARGET_LENGTH)
+        elif audio.shape[0] > 1:
+            audio = audio.mean(dim=0, keepdim=True)
+        if self.augment:
+            return self.augment_batch(audio)[0].cpu()
+        if self.noise_reduce and audio.shape[1] > 0:
+            audio = self._reducer()(audio)
+        return self._front_end()(audio)[0].cpu()
 
 
 def calculate_class_weights(csv_path):

@@ -6,6 +6,7 @@ enqueues on torch's current HIP stream.  No wrapper computes anything itself and
 from __future__ import annotations
 
 import ctypes
+import math
 from typing import List, Optional, Sequence
 
 import torch
@@ -122,6 +123,59 @@ def resample(pcm: torch.Tensor, filt, out: torch.Tensor):
     B, C, T = pcm.shape
     _lib.call("mmsa_resample_fwd", _chk(pcm, name="pcm"), C, T, C * T, _chk(filt["kernT"]), filt["orig"], filt["new"],
               filt["width"], filt["K"], _chk(out, name="out"), out.shape[1], B, _stream())
+    return out
+
+
+def denoise_filters(sr: int, device, time_constant_s: float = 2.0, freq_mask_smooth_hz: float = 500.0,
+                    time_mask_smooth_ms: float = 50.0):
+    """Constants of the spectral gate for sample rate ``sr`` (n_fft 1024, hop 256): one-pole coefficient of the
+    time smoothing and the normalised triangular taps of the mask-smoothing filter (frequency, time)."""
+    t_frames = time_constant_s * sr / 256.0
+    b = (math.sqrt(1.0 + 4.0 * t_frames ** 2) - 1.0) / (2.0 * t_frames ** 2)
+    n_f = int(freq_mask_smooth_hz / (sr / 512.0))
+    n_t = int(time_mask_smooth_ms / ((256.0 / sr) * 1000.0))
+    if n_f < 1 or n_t < 1 or 2 * n_f + 1 > 65 or 2 * n_t + 1 > 33:
+        raise ValueError(f"mask smoothing of {n_f} bins x {n_t} frames is outside the kernel's range")
+
+    def ramp(n):
+        up = torch.arange(1, n + 2, dtype=torch.float64)
+        v = torch.cat([up, up[:-1].flip(0)])
+        return (v / v.sum()).to(F32).to(device)
+
+    return {"b": b, "vf": ramp(n_f), "vt": ramp(n_t)}
+
+
+def denoise(wave: torch.Tensor, filt, tables, out: Optional[torch.Tensor] = None, lens: Optional[torch.Tensor] = None,
+            thresh: float = 2.0, slope: float = 10.0, prop: float = 1.0, pad: int = 30000, chunk: int = 600000):
+    """wave [B, T] -> out [B, T]: non-stationary spectral gating, chunk by chunk for rows longer than ``chunk``.
+    ``lens`` [B] int32: valid lengths of rows that hold utterances of different lengths (T <= chunk then); the output
+    is zero behind each row's length."""
+    if wave.dim() != 2:
+        raise ValueError("wave must be [B, T]")
+    if not wave.is_cuda or wave.dtype != F32 or wave.stride(1) != 1:
+        raise _lib.MmsaError("wave must be a float32 GPU tensor with contiguous rows")
+    B, T = wave.shape
+    if out is None:
+        out = torch.empty((B, T), dtype=F32, device=wave.device)
+    if tuple(out.shape) != (B, T) or out.data_ptr() == wave.data_ptr():
+        raise ValueError("out must be a separate [B, T] tensor")
+    _chk(out, name="out")
+    if lens is not None:
+        if tuple(lens.shape) != (B,) or T > chunk:
+            raise ValueError("lens must be [B] and rows no longer than one chunk")
+        _chk(lens, torch.int32, "lens")
+    for c0 in range(0, T, chunk):
+        L = min(chunk, T - c0)
+        geo = (ctypes.c_int * 3)()
+        need = ctypes.c_long()
+        _lib.call("mmsa_denoise_plan", L, pad, *[ctypes.cast(ctypes.byref(geo, 4 * i), ctypes.c_void_p) for i in range(3)],
+                  ctypes.cast(ctypes.byref(need), ctypes.c_void_p))
+        ws = torch.empty((B * need.value,), dtype=F32, device=wave.device)
+        _lib.call("mmsa_denoise_fwd", wave.data_ptr(), wave.stride(0), T, c0, L, pad, B,
+                  None if lens is None else lens.data_ptr(), _chk(tables["window"]),
+                  _chk(tables["tw512"]), _chk(tables["tw1024"]), _chk(filt["vt"]), filt["vt"].numel(), _chk(filt["vf"]),
+                  filt["vf"].numel(), filt["b"], thresh, slope, prop, ws.data_ptr(), out.data_ptr(), out.stride(0),
+                  _stream())
     return out
 
 

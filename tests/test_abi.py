@@ -120,3 +120,59 @@ def test_synthetic_data_is_deterministic_and_well_formed():
     assert set(np.unique(data.label_batch(0, 200))) == {0, 1, 2}
     rows = data.csv_rows(0, 3)
     assert rows[0] == "Audio_ID;Sentiment;Utterance" and rows[1].split(";")[1] in data.SENTIMENTS
+
+
+def test_noise_gate_plan_constants_and_oracle_behaviour():
+    """Host side of the noise reduction (preprocess.py:142-148): the frame plan of the C ABI agrees with scipy's STFT
+    framing of the padded chunk, the gate constants agree with the oracle's, argument checks reject bad calls, and the
+    oracle itself behaves like a noise gate (a stationary floor is suppressed, a burst passes, silence gives NaN as
+    0/0 does in the package)."""
+    import torch
+    from scipy.signal import stft
+    from mmsa_amd import _lib, ops
+    from oracle import denoise_ref
+    lib = _lib.load()
+    for L, pad in ((66150, 30000), (1, 30000), (3000, 0), (600000, 30000), (16000, 5000)):
+        geo = (ctypes.c_int * 3)()
+        need = ctypes.c_long()
+        _lib.call("mmsa_denoise_plan", L, pad, *[ctypes.cast(ctypes.byref(geo, 4 * i), ctypes.c_void_p) for i in range(3)],
+                  ctypes.cast(ctypes.byref(need), ctypes.c_void_p))
+        nseg, f_lo, nfr = (int(v) for v in geo)
+        if L + 2 * pad <= 200000:
+            _, _, z = stft(np.zeros(L + 2 * pad), nfft=1024, noverlap=768, nperseg=1024, padded=False)
+            assert z.shape == (513, nseg)
+        # frames f_lo .. f_lo+nfr-1 are exactly those whose 1024 samples (centred on 256 f) touch [pad, pad + L)
+        touching = [f for f in range(nseg) if 256 * f + 512 > pad and 256 * f - 512 < pad + L]
+        assert touching == list(range(f_lo, f_lo + nfr))
+        assert need.value == nseg * 516 * 3 + nfr * 1024
+    assert lib.mmsa_denoise_plan(0, 30000, None, None, None, None) == -1
+    geo4 = [ctypes.cast(ctypes.byref((ctypes.c_long * 1)()), ctypes.c_void_p) for _ in range(4)]
+    assert lib.mmsa_denoise_plan(777, 0, *geo4) == -1        # chunk shorter than one STFT frame
+    null = [None] * 4                                  # window, tw512, tw1024, vt
+    assert lib.mmsa_denoise_fwd(None, 100, 100, 0, 100, 30000, 1, None, *null, 9, None, 23, 0.005, 2.0, 10.0, 1.0,
+                                None, None, 100, None) == -1
+    filt = ops.denoise_filters(22050, "cpu")
+    vf, vt = denoise_ref.smoothing_taps(22050)
+    assert filt["vf"].numel() == 23 and filt["vt"].numel() == 9
+    np.testing.assert_allclose(filt["vf"].numpy(), vf / vf.sum(), rtol=1e-6)
+    np.testing.assert_allclose(filt["vt"].numpy(), vt / vt.sum(), rtol=1e-6)
+    assert abs(filt["b"] - denoise_ref.iir_coefficient(22050)) < 1e-15
+    with pytest.raises(ValueError):
+        ops.denoise_filters(400000, "cpu")            # smoothing narrower than one bin
+    with pytest.raises(_lib.MmsaError):
+        ops.denoise(torch.zeros(1, 100), filt, {})    # host tensors are refused: there is no CPU path
+
+    g = np.random.default_rng(0)
+    n = 44100
+    t = np.arange(n) / 22050.0
+    burst = 0.3 * np.sin(2 * np.pi * 440 * t) * ((t > 0.9) & (t < 1.1))
+    y = (burst + 0.02 * g.standard_normal(n)).astype(np.float32)
+    out = denoise_ref.reduce_noise(y, 22050)
+    assert out.dtype == np.float32 and out.shape == y.shape
+    assert out[:15000].std() < 0.5 * y[:15000].std()                    # the floor drops
+    assert out[20500:23500].std() > 0.5 * y[20500:23500].std()          # the onset of the burst passes
+    assert np.isnan(denoise_ref.reduce_noise(np.zeros(3000, np.float32), 22050)).all()
+    # chunked processing only differs from whole-signal processing through the shorter context
+    whole = denoise_ref.reduce_noise(y, 22050)
+    parts = denoise_ref.reduce_noise(y, 22050, chunk_size=20000, padding=15000)
+    assert np.isfinite(parts).all() and np.abs(whole - parts).max() < 0.3 * np.abs(whole).max()

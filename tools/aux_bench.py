@@ -58,13 +58,29 @@ def main():
                                     "frac_of_hbm_peak": round(gbs / HBM_PEAK, 4),
                                     "tflops": round(B * 66150 * 334 * 2 / t / 1e12, 2)}
     # augmented training transform for a batch (waveform augmentation + mel stage with masks)
-    tf = AudioTransform(augment=True, device=DEV)
-    for B in (32, 1024):
+    for gate in (False, True):
+        tf = AudioTransform(augment=True, device=DEV, noise_reduce=gate)
+        for B in (32, 1024):
+            wave = torch.randn(B, 66150, device=DEV) * 0.1
+            drawn = [tf.draw_augmentation(66150) for _ in range(B)]
+            rows, masks = [d[0] for d in drawn], [d[1] for d in drawn]
+            t = timeit(lambda: tf.augment_batch(wave, rows, masks, seed=1), reps=10)
+            out[f"augment_batch{'_gated' if gate else ''}_B{B}"] = {"us": round(t * 1e6, 1), "utt_per_s": round(B / t)}
+    # spectral-gating noise reduction of 3-second utterances.  Bytes moved per utterance with nseg STFT frames of the
+    # padded chunk and nfr frames reaching the output (rows of 516 elements): spectrum written once and read three
+    # times (8 B), smoothed magnitude / mask written twice and read twice (4 B), segments written and read (4 KiB
+    # per frame), waveform in and out.
+    from mmsa_amd.frontend import NoiseReducer
+    nr = NoiseReducer(22050, DEV)
+    nseg, nfr = 1 + (66150 + 60000) // 256, 262
+    per_utt = nseg * 516 * (8 * 3 + 4 * 4) + nfr * (516 * 8 + 4096 * 2) + 66150 * 8
+    for B in (32, 256):
         wave = torch.randn(B, 66150, device=DEV) * 0.1
-        drawn = [tf.draw_augmentation(66150) for _ in range(B)]
-        rows, masks = [d[0] for d in drawn], [d[1] for d in drawn]
-        t = timeit(lambda: tf.augment_batch(wave, rows, masks, seed=1))
-        out[f"augment_batch_B{B}"] = {"us": round(t * 1e6, 1), "utt_per_s": round(B / t)}
+        res = torch.empty(B, 66150, device=DEV)
+        t = timeit(lambda: nr(wave, out=res), reps=10)
+        gbs = B * per_utt / t / 1e9
+        out[f"noise_gate_B{B}"] = {"us": round(t * 1e6, 1), "utt_per_s": round(B / t), "GB_per_s": round(gbs, 1),
+                                   "frac_of_hbm_peak": round(gbs / HBM_PEAK, 4), "bytes_per_utt": per_utt}
     # embedding gather: 1 KiB read + 1 KiB written per token
     table = torch.randn(30522, 256, device=DEV)
     for B in (32, 4096):

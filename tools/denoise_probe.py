@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Error of the GPU noise gate against the float64 oracle on a few signals, and the oracle's CPU rate."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "multimodal-sentiment-analysis_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from mmsa_amd.frontend import NoiseReducer  # noqa: E402
+from oracle import denoise_ref  # noqa: E402
+from test_gpu_ops import _noisy_speechlike  # noqa: E402
+
+nr = NoiseReducer(22050, "cuda")
+for n, seed in ((52000, 3), (66150, 4), (88200, 5), (3000, 6)):
+    y = _noisy_speechlike(2, n, seed)
+    got = nr(torch.from_numpy(y).cuda()).cpu().numpy()
+    t0 = time.time()
+    ref = np.stack([denoise_ref.reduce_noise(y[b].astype(np.float64), 22050) for b in range(2)])
+    dt = (time.time() - t0) / 2
+    err = np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1)
+    print(f"n={n} rel err {err} oracle {dt * 1e3:.1f} ms/utt in-rms {y.std():.4f} out-rms {got.std():.4f}")
+g = np.random.default_rng(0)
+y = (g.standard_normal((2, 66150)) * 0.1).astype(np.float32)
+got = nr(torch.from_numpy(y).cuda()).cpu().numpy()
+ref = np.stack([denoise_ref.reduce_noise(y[b].astype(np.float64), 22050) for b in range(2)])
+print("white noise rel err", np.abs(got - ref).max(axis=1) / np.abs(ref).max(axis=1))
