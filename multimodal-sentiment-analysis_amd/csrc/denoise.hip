@@ -45,6 +45,12 @@ __host__ __device__ inline NrPlan nr_plan(long L, int pad) {
   return p;
 }
 
+// Valid length of row b (clamped to what the buffers were sized for, whatever the caller's array holds).
+__device__ __forceinline__ long row_len(const int* __restrict__ lens, int b, long Lmax) {
+  const long l = lens[b];
+  return l < 1 ? 1 : (l > Lmax ? Lmax : l);
+}
+
 __device__ __forceinline__ void load_twiddles(float2* tws, const float* __restrict__ tw512, int t) {
   const float2 w = make_float2(tw512[2 * t], tw512[2 * t + 1]);
   tws[t] = w;
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(256) void nr_stft_kernel(const float* __restrict__ 
 #pragma unroll
   for (int r = 0; r < 8; ++r) wv[r] = *reinterpret_cast<const float2*>(window + 2 * (j + 64 * r));
   const float* w = wave + (long)b * stride;
-  if (lens) { L = lens[b]; T = L; }                  // a shorter row: its own chunk, zeros behind it
+  if (lens) { L = row_len(lens, b, L); T = L; }      // a shorter row: its own chunk, zeros behind it
   const long N = L + 2L * pad;
   {
     // samples the group's frames cover, in signal coordinates; a group that sees only padding writes zero spectra
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(1024) void nr_gate_kernel(const float2* __restrict_
   const int nw = blockDim.x >> 6;
   const int k = min(blockIdx.x * 64 + lane, NB - 1);       // lanes past the last bin shadow it (same values stored)
   const long row0 = (long)blockIdx.y * nseg * PITCH;       // rows are laid out for the longest utterance ...
-  if (lens) nseg = nr_plan(lens[blockIdx.y], pad).nseg;    // ... and filtered over their own frames
+  if (lens) nseg = min(nseg, nr_plan(row_len(lens, blockIdx.y, 1L << 30), pad).nseg);   // ... filtered over their own
   const int seg = ((nseg + nw - 1) / nw + U - 1) / U * U;
   const int s0 = sg * seg;
   const int len = max(0, min(seg, nseg - s0));
@@ -239,9 +245,9 @@ __global__ __launch_bounds__(256) void nr_synth_kernel(const float2* __restrict_
   const int f = f_lo + lf;
   int nseg_b = nseg, nfr_b = nfr;                    // this utterance's own frame counts
   if (lens) {
-    const NrPlan pl = nr_plan(lens[b], pad);
-    nseg_b = pl.nseg;
-    nfr_b = pl.nfr;
+    const NrPlan pl = nr_plan(row_len(lens, b, 1L << 30), pad);
+    nseg_b = min(nseg, pl.nseg);
+    nfr_b = min(nfr, pl.nfr);
   }
   const bool live = lf < nfr_b;
   load_twiddles(tws, tw512, t);
@@ -326,11 +332,12 @@ __global__ __launch_bounds__(256) void nr_ola_kernel(const float* __restrict__ s
   if (i >= L) return;
   const int b = blockIdx.y;
   if (lens) {
-    if (i >= lens[b]) {                              // behind a shorter row: zeros
+    const long len = row_len(lens, b, L);
+    if (i >= len) {                                  // behind a shorter row: zeros
       out[(long)b * out_stride + c0 + i] = 0.f;
       return;
     }
-    nseg = nr_plan(lens[b], pad).nseg;
+    nseg = min(nseg, nr_plan(len, pad).nseg);
   }
   const long q = (long)pad + i;                      // position in the padded chunk
   const long p = q + NFFT / 2;                       // position in the boundary-extended chunk

@@ -155,7 +155,11 @@ class NoiseReducer:
         if wave.stride(1) != 1:
             wave = wave.contiguous()
         if lens is not None:
-            lens = torch.as_tensor(lens, dtype=torch.int32).to(self.device).contiguous()
+            host = torch.as_tensor(lens, dtype=torch.int64).cpu()
+            # checked on the host: the kernels index rows by these lengths
+            if host.shape != (wave.shape[0],) or int(host.min()) < 1 or int(host.max()) > wave.shape[1]:
+                raise ValueError("lens must hold one length in 1..n_samples per row")
+            lens = host.to(dtype=torch.int32, device=self.device).contiguous()
         return ops.denoise(wave, self.filters, self.tables, out=out, lens=lens)
 
 

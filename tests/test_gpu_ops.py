@@ -158,6 +158,9 @@ def test_noise_reduction_rows_of_different_lengths_and_chunks():
         assert torch.equal(got[b, :n], alone)
         assert not got[b, n:].any()
         check(alone, torch.from_numpy(denoise_ref.reduce_noise(y[b, :n].astype(np.float64), 22050)), 5e-6)
+    for bad in ([40001, 5, 5], [0, 5, 5], [5, 5]):    # lengths are checked on the host before any launch
+        with pytest.raises(ValueError):
+            nr(x, lens=bad)
     # chunked: 3 chunks of 16000 with 5000 samples of context
     ch = ops.denoise(x, nr.filters, nr.tables, chunk=16000, pad=5000).cpu()
     for b in range(3):
