@@ -95,6 +95,9 @@ MMSA_API int mmsa_conv_pack_weights(const float* w, float* fwd, float* dgrad, in
 MMSA_API int mmsa_conv_pack_desc_bytes(void);
 MMSA_API int mmsa_conv_pack_weights_multi(const void* descs, int n, void* stream);
 /* tile height the forward kernel uses for this geometry; statistics rows = B * ceil(H*W / tile height) */
+/* LDS ring depth the forward / data-gradient launch picks for this geometry and number of problems per launch (the
+ * last template argument of the kernel name a profiler prints) */
+MMSA_API int mmsa_conv_ring_buffers(int B, int H, int W, int Cout, int nproblems);
 MMSA_API int mmsa_conv_tile_rows(int B, int H, int W, int Cout);
 /* Y[B,H,W,Cout] (= or +=) sum_t X[b, h+dh[t], w+dw[t], :] . Wp[t][:, :]; reads outside the image are zero.
  * dh/dw are host arrays.  stats (optional): [2][Cout][B*tiles] per-tile column sums and sums of squares. */

@@ -129,7 +129,7 @@ __device__ unsigned long long* g_lab_stamps;
 #define LAB_STAMP(i)
 #endif
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STATS, bool ACCUM>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STATS, bool ACCUM, int NB>
 __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict__ X, const float* __restrict__ Wp0,
                                                          float* __restrict__ Y0, float* __restrict__ stats,
                                                          const ConvGeom g, int tiles_per_img, const ConvMulti multi) {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
   constexpr int B_LD = BN / 32;
   constexpr int LD = A_LD + B_LD;
   constexpr int BUF_FLOATS = (BM + BN) * KC;   // one LDS buffer: A rows then B rows of one 32-channel chunk
-  constexpr int NBUF = igemm_nbuf(BM, BN);     // ring of LDS buffers; a chunk is requested NBUF-1 steps ahead
+  constexpr int NBUF = NB;                     // ring of LDS buffers; a chunk is requested NBUF-1 steps ahead
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   LAB_STAMP(0);
@@ -709,20 +709,48 @@ int fill_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout, int ntaps, co
   return MMSA_OK;
 }
 
-template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM>
-int launch_igemm_one(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int tiles, dim3 grid,
-                     const ConvMulti& multi, hipStream_t s) {
-  constexpr size_t shmem = igemm_nbuf(BM, BN) * (size_t)(BM + BN) * KC * sizeof(float);
+template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM, int NB>
+int launch_igemm_ring(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int tiles, dim3 grid,
+                      const ConvMulti& multi, hipStream_t s) {
+  constexpr size_t shmem = NB * (size_t)(BM + BN) * KC * sizeof(float);
   static bool attr_set = false;   // raising the dynamic-LDS limit is sticky per kernel; benign if raced
   if (shmem > 48 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM, NB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
       return MMSA_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM>), grid, dim3(512), shmem, s, X, Wp, Y,
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM, NB>), grid, dim3(512), shmem, s, X, Wp, Y,
                      stats, g, tiles, multi);
   return mmsa_launch_status();
+}
+
+// Ring depth per launch.  The 64 x 64 tile takes 16 KiB per buffer: five buffers (two workgroups per CU, deeper
+// prefetch) unless a ring of three (three workgroups per CU) saves a whole round of workgroups over the chip's 256
+// CUs -- the 2080-position maps, whose 1056 workgroups need three rounds of 512 but two of 768 (5-9 % faster there;
+// on the smaller maps, which fit one round either way, the shallower ring loses 3-8 %).
+int pick_ring(int BM, int BN, long blocks) {
+  const int nb = igemm_nbuf(BM, BN);
+  if (BM == 64 && BN == 64 && nb > 3) {
+    static int ring3 = -1;   // MMSA_IGEMM_RING3=0 keeps five buffers everywhere (A/B aid)
+    if (ring3 < 0) {
+      const char* e = getenv("MMSA_IGEMM_RING3");
+      ring3 = e ? atoi(e) : 1;
+    }
+    if (ring3 && (blocks + 767) / 768 < (blocks + 511) / 512) return 3;
+  }
+  return nb;
+}
+
+template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM>
+int launch_igemm_one(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int tiles, dim3 grid,
+                     const ConvMulti& multi, hipStream_t s) {
+  constexpr int NB = igemm_nbuf(BM, BN);
+  if constexpr (BM == 64 && BN == 64 && NB > 3) {
+    if (pick_ring(BM, BN, (long)grid.x * grid.y * grid.z) == 3)
+      return launch_igemm_ring<BM, BN, WM_, WN_, STATS, ACCUM, 3>(X, Wp, Y, stats, g, tiles, grid, multi, s);
+  }
+  return launch_igemm_ring<BM, BN, WM_, WN_, STATS, ACCUM, NB>(X, Wp, Y, stats, g, tiles, grid, multi, s);
 }
 
 template <int BM, int BN, int WM_, int WN_>
@@ -765,6 +793,15 @@ static int pick_bm(int B, int H, int W, int Cout) {
   // 64 rows are 15-20 % faster on the 2080-position maps, 2x faster on the 128/512-position ones)
   const long blocks128 = (long)B * mmsa_cdiv((long)H * W, 128) * (Cout / 64 > 0 ? Cout / 64 : 1);
   return blocks128 >= 2048 ? 128 : 64;
+}
+
+// LDS ring depth (last template argument of the kernel instantiation) that a launch of `nproblems` convolutions with
+// this geometry uses: part of the kernel's name in profiler output.
+MMSA_EXPORT int mmsa_conv_ring_buffers(int B, int H, int W, int Cout, int nproblems) {
+  MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && nproblems > 0);
+  const int bm = Cout % 64 ? 128 : pick_bm(B, H, W, Cout), bn = Cout % 64 ? 32 : 64;
+  const long blocks = (long)B * mmsa_cdiv((long)H * W, bm) * (Cout / bn) * nproblems;
+  return pick_ring(bm, bn, blocks);
 }
 
 MMSA_EXPORT int mmsa_conv_tile_rows(int B, int H, int W, int Cout) {

@@ -36,11 +36,12 @@ def _prof_begin(kind: str, flops: float):
     return e
 
 
-def _igemm_name(bm, bn, stats, accum) -> str:
+def _igemm_name(bm, bn, stats, accum, geom, nproblems=1) -> str:
     """Name of the kernel instantiation mmsa_conv_fwd launches for this tile (as rocprofv3 prints it, without spaces)."""
     wm, wn = (4, 1) if bn == 32 else (2, 2)
-    return "conv_igemm_kernel<%d,%d,%d,%d,%s,%s>" % (bm, bn, wm, wn, "true" if stats else "false",
-                                                      "true" if accum else "false")
+    ring = _lib.query("mmsa_conv_ring_buffers", *geom, nproblems)
+    return "conv_igemm_kernel<%d,%d,%d,%d,%s,%s,%d>" % (bm, bn, wm, wn, "true" if stats else "false",
+                                                         "true" if accum else "false", ring)
 
 
 def _stream() -> int:
@@ -243,7 +244,7 @@ def conv_fwd(X, Wp, Y, stats, B, H, W, Cin, Cout, taps, negate=False, accumulate
     ev = None
     if PROFILE is not None:
         bm, bn = (128, 32) if Cout % 64 else (conv_tile_rows(B, H, W, Cout), 64)
-        kind = _igemm_name(bm, bn, stats is not None, accumulate)
+        kind = _igemm_name(bm, bn, stats is not None, accumulate, (B, H, W, Cout))
         ev = _prof_begin(kind, 2.0 * B * H * W * Cin * Cout * len(taps))
     _lib.call("mmsa_conv_fwd", _chk(X), _chk(Wp), _chk(Y), _opt(stats), B, H, W, Cin, Cout, len(taps),
               _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), int(accumulate), _stream())
@@ -260,7 +261,8 @@ def conv_fwd_dual(X, Wp, X2, Wp2, Y, B, H, W, Cin, Cout, taps, negate=False):
     ev = None
     if PROFILE is not None:
         bm, bn = (128, 32) if Cout % 64 else (conv_tile_rows(B, H, W, Cout), 64)
-        ev = _prof_begin(_igemm_name(bm, bn, False, False), 2.0 * B * H * W * Cin * Cout * (len(taps) + 1))
+        ev = _prof_begin(_igemm_name(bm, bn, False, False, (B, H, W, Cout)),
+                         2.0 * B * H * W * Cin * Cout * (len(taps) + 1))
     _lib.call("mmsa_conv_fwd_dual", _chk(X), _chk(Wp), _chk(X2), _chk(Wp2), _chk(Y), B, H, W, Cin, Cout, len(taps),
               _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), _stream())
     if ev is not None:
@@ -285,7 +287,7 @@ def conv_fwd_multi(X, Wps, Ys, ntaps_list, B, H, W, Cin, Cout, taps, tap0_list=N
             raise ValueError("conv_fwd_multi: statistics buffers have the wrong size")
     ev = None
     if PROFILE is not None:
-        ev = _prof_begin(_igemm_name(bm, 64, stats_list is not None, False),
+        ev = _prof_begin(_igemm_name(bm, 64, stats_list is not None, False, (B, H, W, Cout), n),
                          2.0 * B * H * W * Cin * Cout * sum(ntaps_list))
     _lib.call("mmsa_conv_fwd_multi", _chk(X), _parr([_chk(w) for w in Wps]), _parr([_chk(y) for y in Ys]),
               _iarr(ntaps_list), _iarr(tap0_list), None if stats_list is None else _parr([_chk(t) for t in stats_list]),
