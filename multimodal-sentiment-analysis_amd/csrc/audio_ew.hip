@@ -624,12 +624,14 @@ __global__ void se_wgrad_kernel(const float* __restrict__ du, const float* __res
   if (i < n) {  // dW2 [C][Ch]
     const int c = i / Ch, j = i - c * Ch;
     float s = 0.f;
+#pragma unroll 8   // the operands of eight utterances are requested together; the sum keeps its order
     for (int b = 0; b < B; ++b) s = fmaf(du[(long)b * C + c], hid[(long)b * Ch + j], s);
     dW2[i] = s;
   } else if (i < 2 * n) {  // dW1 [Ch][C]
     const int k = i - n;
     const int j = k / C, c = k - j * C;
     float s = 0.f;
+#pragma unroll 8
     for (int b = 0; b < B; ++b) s = fmaf(dhp[(long)b * Ch + j], gap[(long)b * C + c], s);
     dW1[k] = s;
   }

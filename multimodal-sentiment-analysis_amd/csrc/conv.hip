@@ -610,35 +610,41 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pair_kernel(const float* __
     conv_wgrad_body<1>(X, a1.dY, a1.partial, g1, a1.R, a1.nstrips, a1.strips_per_img, a1.nsplit);
 }
 
-// partial[slab][tap][Cin][Cout] -> dW[Cout][Cin][ntaps]  (+= when accumulate).  64 outputs per workgroup, the
-// NW (4 or 16, by the number of slabs) waves take interleaved slabs (four independent loads each per round) and are combined in fixed order
-// through LDS.
+// partial[slab][tap][Cin][Cout] -> dW[Cout][Cin][ntaps]  (+= when accumulate).  256 outputs per workgroup (four
+// consecutive ones per lane, read as one 16-byte piece per slab); the NW (4 or 16, by the number of slabs) waves take
+// interleaved slabs (four independent loads each per round) and are combined in fixed order through LDS.
+constexpr int RED_OUT = 256;   // outputs per workgroup of the reduction
 template <int NW>
 __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partial, float* __restrict__ dW, int nslabs,
                                                   int ntaps, int Cin, int Cout, int accumulate, long block) {
-  __shared__ float red[NW][64];
-  const long total = (long)ntaps * Cin * Cout;
+  __shared__ f32x4 red[NW][64];
+  const long total = (long)ntaps * Cin * Cout;         // a multiple of 4 (Cout is a multiple of 64)
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const long i = block * 64 + lane;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const long i = block * RED_OUT + 4 * lane;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 s0 = zero, s1 = zero, s2 = zero, s3 = zero;
   if (i < total) {
+    const float* src = partial + i;
     int k = w;
     for (; k + 3 * NW < nslabs; k += 4 * NW) {
-      s0 += partial[(long)k * total + i];
-      s1 += partial[(long)(k + NW) * total + i];
-      s2 += partial[(long)(k + 2 * NW) * total + i];
-      s3 += partial[(long)(k + 3 * NW) * total + i];
+      s0 += *reinterpret_cast<const f32x4*>(src + (long)k * total);
+      s1 += *reinterpret_cast<const f32x4*>(src + (long)(k + NW) * total);
+      s2 += *reinterpret_cast<const f32x4*>(src + (long)(k + 2 * NW) * total);
+      s3 += *reinterpret_cast<const f32x4*>(src + (long)(k + 3 * NW) * total);
     }
-    for (; k < nslabs; k += NW) s0 += partial[(long)k * total + i];
+    for (; k < nslabs; k += NW) s0 += *reinterpret_cast<const f32x4*>(src + (long)k * total);
   }
   red[w][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (w == 0 && i < total) {
+  // 256 threads finish one output each: thread t takes component t & 3 of lane t >> 2
+  const int t = threadIdx.x;
+  const long io = block * RED_OUT + t;
+  if (t < RED_OUT && io < total) {
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < NW; ++k) s += red[k][lane];
-    const int co = (int)(i % Cout);
-    const long r = i / Cout;
+    for (int k = 0; k < NW; ++k) s += red[k][t >> 2][t & 3];
+    const int co = (int)(io % Cout);
+    const long r = io / Cout;
     const int ci = (int)(r % Cin);
     const int tp = (int)(r / Cin);
     float* dst = dW + ((long)co * Cin + ci) * ntaps + tp;
@@ -957,7 +963,8 @@ MMSA_EXPORT int mmsa_conv_wgrad_pair(const float* X, const float* dY9, const flo
   const WgradArgs a1{dY1, ws1, p1.R, p1.nstrips, p1.strips_per_img, p1.nsplit};
   dim3 grid((Cin / 32) * (Cout / 64), p9.nsplit > p1.nsplit ? p9.nsplit : p1.nsplit, 2);
   hipLaunchKernelGGL(conv_wgrad_pair_kernel, grid, dim3(256), shmem, s, X, g9, g1, a9, a1);
-  const int blocks9 = (int)((9L * Cin * Cout + 63) / 64), blocks1 = (int)(((long)Cin * Cout + 63) / 64);
+  const int blocks9 = (int)((9L * Cin * Cout + RED_OUT - 1) / RED_OUT);
+  const int blocks1 = (int)(((long)Cin * Cout + RED_OUT - 1) / RED_OUT);
   if (p9.nslabs > 64 || p1.nslabs > 64)
     hipLaunchKernelGGL(wgrad_reduce_pair_kernel<16>, dim3(blocks9 + blocks1), dim3(1024), 0, s, ws9, dW9, p9.nslabs, ws1,
                        dW1, p1.nslabs, blocks9, Cin, Cout);
@@ -976,10 +983,11 @@ MMSA_EXPORT int mmsa_conv_wgrad_reduce(const float* workspace, float* dW, int B,
   const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, ntaps);
   const long total = (long)ntaps * Cin * Cout;
   if (p.nslabs > 64)
-    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0,
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3((unsigned)((total + RED_OUT - 1) / RED_OUT)), dim3(1024), 0,
                        mmsa_stream(stream), workspace, dW, p.nslabs, ntaps, Cin, Cout, accumulate);
   else
-    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, mmsa_stream(stream),
+    hipLaunchKernelGGL(wgrad_reduce_kernel<4>, dim3((unsigned)((total + RED_OUT - 1) / RED_OUT)), dim3(256), 0,
+                       mmsa_stream(stream),
                        workspace, dW, p.nslabs, ntaps, Cin, Cout, accumulate);
   return mmsa_launch_status();
 }
