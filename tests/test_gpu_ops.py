@@ -417,3 +417,19 @@ def test_audio_transform_error_contract():
     assert out.shape == (1, 64, 130) and not out.any()
     with pytest.raises(Exception):
         AudioTransform(device=DEV, strict=True)(bad)
+
+
+@pytest.mark.parametrize("n", [1, 255, 1024, 600100])
+def test_noise_reduction_edge_lengths(n):
+    """One sample, less than a hop, exactly one frame, and a signal one hundred samples longer than a chunk (its second
+    chunk holds 100 samples and sees 30 000 samples of the first as context)."""
+    from mmsa_amd.frontend import NoiseReducer
+    from oracle import denoise_ref
+    g = np.random.default_rng(n)
+    y = (0.1 * g.standard_normal(n) + 0.2 * np.sin(np.arange(n) * 0.05) * (np.arange(n) > n // 2)).astype(np.float32)
+    got = NoiseReducer(22050, DEV)(torch.from_numpy(y)[None].to(DEV)).cpu()[0]
+    ref = denoise_ref.reduce_noise(y.astype(np.float64), 22050)
+    assert got.shape == (n,) and bool(torch.isfinite(got).all())
+    # relative to the input's peak: a one-sample signal is gated to (almost) nothing
+    err = float((got.double() - torch.from_numpy(ref)).abs().max()) / float(np.abs(y).max())
+    assert err < 5e-6, err
