@@ -108,6 +108,14 @@ MMSA_API int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* sta
 MMSA_API int mmsa_conv_fwd_dual(const float* X, const float* Wp, const float* X2, const float* Wp2, float* Y, int B,
                                 int H, int W, int Cin, int Cout, int ntaps, const int* dh_host, const int* dw_host,
                                 void* stream);
+/* mmsa_conv_fwd_dual with the K range split over two workgroups per output tile (taps 0..4 | taps 5..8 plus the second
+ * pair), for maps with at most one tile per CU of the chip (mmsa_conv_fwd_dual_prefers_split: 1 / 0).
+ * Y MUST BE ZERO on entry: both halves add their part with hardware float atomics -- two addends per element, so the
+ * result does not depend on their order.  3x3 offsets only, Cout a multiple of 64. */
+MMSA_API int mmsa_conv_fwd_dual_prefers_split(int B, int H, int W, int Cout);
+MMSA_API int mmsa_conv_fwd_dual_split(const float* X, const float* Wp, const float* X2, const float* Wp2,
+                                      float* Y_zeroed, int B, int H, int W, int Cin, int Cout, int ntaps,
+                                      const int* dh_host, const int* dw_host, void* stream);
 /* n (<= 4) convolutions of one input in one launch -- the text branch's filter widths (multimodal_model.py:186-188),
  * or a residual block's first 3x3 convolution together with its 1x1 shortcut (:48-49,64-68): problem i uses
  * Wp_host[i], entries tap0_host[i] .. tap0_host[i] + ntaps_host[i] - 1 of the offset table (tap0_host null: 0) and

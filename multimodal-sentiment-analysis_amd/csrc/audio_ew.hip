@@ -499,6 +499,19 @@ __global__ __launch_bounds__(256) void res_pool_bwd_kernel(const float* __restri
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dz + offs[k]) = o[k];
+    // positions outside every pooling window (last column of an odd width, last row of an odd height) receive no
+    // routed gradient: the window next to them writes their zeros
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const bool edge_w = (W & 1) && w2 == W2 - 1, edge_h = (H & 1) && h2 == H2 - 1;
+    if (edge_w) {
+      *reinterpret_cast<f32x4*>(dz + (((long)b * H + 2 * h2) * W + W - 1) * C + c) = zero;
+      *reinterpret_cast<f32x4*>(dz + (((long)b * H + 2 * h2 + 1) * W + W - 1) * C + c) = zero;
+    }
+    if (edge_h) {
+      *reinterpret_cast<f32x4*>(dz + (((long)b * H + H - 1) * W + 2 * w2) * C + c) = zero;
+      *reinterpret_cast<f32x4*>(dz + (((long)b * H + H - 1) * W + 2 * w2 + 1) * C + c) = zero;
+      if (edge_w) *reinterpret_cast<f32x4*>(dz + (((long)b * H + H - 1) * W + W - 1) * C + c) = zero;
+    }
   }
   float* mine = red + (long)pl * 3 * C;
   *reinterpret_cast<f32x4*>(mine + c) = a1;
@@ -917,9 +930,6 @@ MMSA_EXPORT int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const f
   float* dg = dhp + (long)B * Ch;
   float* tab = dg + (long)B * C;
   float* dz = d_sc;  // pass A writes dz where d_sc will end up; pass B converts it in place
-  if ((H & 1) || (W & 1)) {  // positions outside every pooling window receive no routed gradient
-    if (hipMemsetAsync(dz, 0, (size_t)B * H * W * C * sizeof(float), s) != hipSuccess) return MMSA_ERR_LAUNCH;
-  }
   hipLaunchKernelGGL(res_pool_bwd_kernel, dim3(B * nchunks), dim3(256), (size_t)planes * 3 * C * sizeof(float), s, dout,
                      c2, sc, coeff2, coeffs, gate, dz, partial, H, W, C, chunk, nchunks);
   hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), 0, s, partial, nchunks, coeff2, gate, hid, W1, W2, A, du, dhp,

@@ -206,8 +206,12 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
                     training)
     f1 = fork(ws, d_out.device, enable=FORK_WGRAD).mark()           # d_c1 is ready
     if need_dx:
-        # 3x3 branch and 1x1 shortcut in one launch (one K loop over both operand pairs)
-        ops.conv_fwd_dual(d_c1, s.w1d, d_sc, s.wsd, d_in, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
+        # 3x3 branch and 1x1 shortcut in one launch (one K loop over both operand pairs); on a map with few output
+        # tiles the K range is split over two workgroups per tile, which add into the map the forward pass zeroed
+        if ws.persistent and ops.conv_dual_prefers_split(B, H, W, Cin):
+            ops.conv_fwd_dual_split(d_c1, s.w1d, d_sc, s.wsd, d_in, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
+        else:
+            ops.conv_fwd_dual(d_c1, s.w1d, d_sc, s.wsd, d_in, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
     with f1:
         wgrad_conv1_shortcut()
     return d_in
@@ -243,6 +247,13 @@ def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Works
     h, w, cin = H // 2, W // 2, 32
     with fpack:
         packs = pack_all(m, need_grad, ws)
+        if need_grad and ws.persistent:
+            # input-gradient maps that the backward pass fills by atomic adds of two half-sums start from zero
+            hh, ww, cc = h, w, cin
+            for i in range(3):
+                if ops.conv_dual_prefers_split(B, hh, ww, cc):
+                    ws.buf(f"rb{i + 1}.d_in", (B, hh, ww, cc)).zero_()
+                hh, ww, cc = hh // 2, ww // 2, cc * 2
     fpack.join()
     for i, blk in enumerate((m.res_block1, m.res_block2, m.res_block3)):
         cout = blk.conv1.weight.shape[0]

@@ -269,6 +269,28 @@ def conv_fwd_dual(X, Wp, X2, Wp2, Y, B, H, W, Cin, Cout, taps, negate=False):
         ev.record()
 
 
+def conv_dual_prefers_split(B, H, W, Cout) -> bool:
+    """Whether :func:`conv_fwd_dual` should run with its K range split in two for this geometry (few output tiles)."""
+    return bool(_lib.query("mmsa_conv_fwd_dual_prefers_split", B, H, W, Cout))
+
+
+def conv_fwd_dual_split(X, Wp, X2, Wp2, Y, B, H, W, Cin, Cout, taps, negate=False):
+    """:func:`conv_fwd_dual` with two workgroups per output tile adding into ``Y``, which must be zero on entry."""
+    if (X.numel() != B * H * W * Cin or X2.numel() != X.numel() or Y.numel() != B * H * W * Cout
+            or Wp.numel() != len(taps) * Cin * Cout or Wp2.numel() != Cin * Cout or len(taps) != 9):
+        raise ValueError("conv_fwd_dual_split: operand sizes do not match the geometry")
+    sgn = -1 if negate else 1
+    ev = None
+    if PROFILE is not None:
+        ring = _lib.query("mmsa_conv_ring_buffers", B, H, W, Cout, 2)
+        ev = _prof_begin("conv_igemm_kernel<64,64,2,2,false,true,%d>" % ring,
+                         2.0 * B * H * W * Cin * Cout * (len(taps) + 1))
+    _lib.call("mmsa_conv_fwd_dual_split", _chk(X), _chk(Wp), _chk(X2), _chk(Wp2), _chk(Y), B, H, W, Cin, Cout,
+              len(taps), _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), _stream())
+    if ev is not None:
+        ev.record()
+
+
 def conv_fwd_multi(X, Wps, Ys, ntaps_list, B, H, W, Cin, Cout, taps, tap0_list=None, stats_list=None):
     """Several convolutions of X in one launch; problem i uses offsets tap0_list[i] .. + ntaps_list[i] of ``taps``
     (from 0 when tap0_list is None) and, with stats_list, writes its per-tile statistics like :func:`conv_fwd`."""

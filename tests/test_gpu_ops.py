@@ -433,3 +433,26 @@ def test_noise_reduction_edge_lengths(n):
     # relative to the input's peak: a one-sample signal is gated to (almost) nothing
     err = float((got.double() - torch.from_numpy(ref)).abs().max()) / float(np.abs(y).max())
     assert err < 5e-6, err
+
+
+def test_split_k_dual_convolution_matches_the_unsplit_launch():
+    """3x3 + 1x1 data gradient with the K range split over two workgroups per tile (atomic adds of two half-sums onto a
+    zeroed map): equal to the one-workgroup launch up to the changed association of the sum, and bit-reproducible
+    (two addends commute)."""
+    ops = _ops()
+    B, H, W, Cin, Cout = 32, 8, 16, 256, 128
+    assert ops.conv_dual_prefers_split(B, H, W, Cout) and not ops.conv_dual_prefers_split(B, 32, 65, 64)
+    g = torch.Generator().manual_seed(4)
+    X = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+    X2 = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+    Wp = (torch.randn(9, Cout, Cin, generator=g) * 0.05).to(DEV)
+    Wp2 = (torch.randn(Cout, Cin, generator=g) * 0.05).to(DEV)
+    ref = torch.empty(B, H, W, Cout, device=DEV)
+    ops.conv_fwd_dual(X, Wp, X2, Wp2, ref, B, H, W, Cin, Cout, ops.TAPS3X3, negate=True)
+    outs = []
+    for _ in range(2):
+        y = torch.zeros(B, H, W, Cout, device=DEV)
+        ops.conv_fwd_dual_split(X, Wp, X2, Wp2, y, B, H, W, Cin, Cout, ops.TAPS3X3, negate=True)
+        outs.append(y)
+    check(outs[0], ref, 1e-5)          # fp32 sums over K = 2560 in two associations
+    assert torch.equal(outs[0], outs[1])

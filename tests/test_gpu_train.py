@@ -35,7 +35,11 @@ def test_three_steps_match_oracle(modality):
         loss = ts.step(**_step_inputs(modality, {k: v.to(DEV) for k, v in b.items()}))
         r = ref.step(b["audio"], b["input_ids"], b["label"], *(draws[s] if modality == "both" else (False, False)))
         assert abs(float(loss) - r["loss"]) < 1e-4, (s, float(loss), r["loss"])
-        assert abs(float(ts.grad_norm()) - r["grad_norm"]) < 1e-3 * max(1.0, r["grad_norm"])
+        # the first step's norm agrees to rounding; from the second on the two runs no longer hold the same weights
+        # (Adam's first update is +-lr per element, with the sign of gradients that are rounding noise), and the norm
+        # of the gradient follows the weights: 1e-3 measured at the third step
+        tol = 1e-5 if s == 0 else 2e-3
+        assert abs(float(ts.grad_norm()) - r["grad_norm"]) < tol * max(1.0, r["grad_norm"])
     # After three Adam steps the accumulated UPDATE of every tensor must agree (relative L2).  Adam divides by
     # sqrt(v), so elements whose gradient is rounding noise move by +-lr with a sign that differs between any
     # two fp32 implementations; the L2 metric over the whole tensor is insensitive to those few elements.
