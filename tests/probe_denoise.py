@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Error of the GPU noise gate against the float64 oracle on a few signals, and the oracle's CPU rate."""
+"""Not collected by pytest: prints the error of the GPU noise gate against the float64 oracle on a few signals and
+the oracle's CPU rate (python tests/probe_denoise.py on a GPU box)."""
 import os
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "multimodal-sentiment-analysis_amd"), os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "multimodal-sentiment-analysis_amd"), os.path.dirname(os.path.abspath(__file__))):
     sys.path.insert(0, p)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
