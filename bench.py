@@ -181,7 +181,9 @@ def main():
             "metric": "train utterances/sec, CNN --modality both", "value": round(value, 1), "unit": "utt/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded tone + noise waveforms already at 22.05 kHz, random token ids and labels, "
+                    "random-init weights; resampling and noise reduction are not part of the timed step)",
             "config": {"workload": "CNN --modality both train step (log-mel front end + fwd + bwd + L2 term + clip 1.0 "
                                    "+ AdamW lr 1e-3 wd 1e-4), batch 32/GPU, 3 s @ 22.05 kHz waveforms, 128 tokens, "
                                    "vocab 30522, fusion dropout 0.6, modality dropout 0.3", "global_batch": world * PER_GPU_BATCH,
