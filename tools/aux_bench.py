@@ -100,6 +100,24 @@ def main():
     gbs = nparam * 36 / t / 1e9
     out["clip_adamw"] = {"us": round(t * 1e6, 1), "GB_per_s": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK, 4),
                          "bytes_per_param": 36}
+    # the whole chain from decoded 16 kHz PCM: mono / resample (full length) -> noise gate -> training step (mel stage,
+    # forward, backward, clip, AdamW), 32 utterances of 4 s
+    model.train()
+    ts2 = TrainStep(model, frontend=fe, use_graph=True)
+    b32 = data.make_batch(0, 32, with_wave=True)
+    ids32 = torch.from_numpy(b32["input_ids"]).to(DEV)
+    lab32 = torch.from_numpy(b32["label"]).to(DEV)
+    pcm = torch.randn(32, 1, 64000, device=DEV) * 0.1
+    n_res = rs.resampled_length(64000)
+    res = torch.empty(32, n_res, device=DEV)
+    den = torch.empty(32, n_res, device=DEV)
+
+    def chain():
+        rs(pcm, n_out=n_res, out=res)
+        nr(res, out=den)
+        ts2.step(wave=den[:, :66150], input_ids=ids32, labels=lab32)
+    t = timeit(chain, reps=20, warm=5)
+    out["pcm16k_to_train_step_B32"] = {"ms": round(t * 1e3, 3), "utt_per_s": round(32 / t)}
     # inference, config 5: eval forward of 1024 utterances (front end included), predictions stay on the device
     model.eval()
     b = data.make_batch(0, 64, with_wave=True)
