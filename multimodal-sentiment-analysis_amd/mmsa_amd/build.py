@@ -53,7 +53,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if force or jobs or _stale(LIB_PATH, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH])
+        # link inside the object directory (hipcc leaves its unbundled temporaries beside the output), then move
+        tmp = os.path.join(OBJ_DIR, "libmmsa_hip.so")
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp])
+        os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 

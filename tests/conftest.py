@@ -32,7 +32,8 @@ def golden():
 
 def seeded_model(modality, vocab=None, dropout0=True, **kw):
     """Seed-42 construction of the drop-in model (its initial weights equal the reference's, which
-    tests/test_init_parity.py proves against fingerprints captured from the reference)."""
+    tests/test_oracle_golden.py::test_seeded_init_matches_reference proves against fingerprints captured from the
+    reference)."""
     from mmsa_amd.model import MultimodalSentimentModel
     torch.manual_seed(42)
     args = dict(modality=modality)
