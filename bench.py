@@ -96,7 +96,8 @@ def main():
     torch.manual_seed(42)
     # the training driver's defaults (multimodal_train.py:71-76,457-468): dropout 0.5 / 0.3 / 0.6, modality dropout 0.3
     model = MultimodalSentimentModel("both", audio_dropout=0.5, text_dropout=0.3, fusion_dropout=0.6).to(dev).train()
-    torch.manual_seed(42 + rank)     # identical replicas, per-rank stream for the modality-dropout draws (rank 0 = 42)
+    # every rank keeps the same host generator: one modality-dropout decision per global batch, as the reference
+    # makes one per batch (multimodal_model.py:264-268); TrainStep verifies the ranks agree
     fe = LogMelFrontEnd(dev)
     use_graph = not args.no_graph
     ts = TrainStep(model, lr=1e-3, weight_decay=1e-4, max_norm=1.0, frontend=fe, use_graph=use_graph)

@@ -196,11 +196,13 @@ MMSA_API int mmsa_bias_relu_maxtime_multi(const float* const* y_host, const floa
                                           const int* Lout_host, int n, float* feat, int* arg, int B, int L, int F,
                                           int ldf, void* stream);
 /* sparse backward of conv + ReLU + max over time + gather; ksize/feat_off/wp/dW/dbias are host arrays
- * (wp/dW/dbias: host arrays of device pointers); dtable is accumulated into; rows == padding_idx get nothing */
+ * (wp/dW/dbias: host arrays of device pointers); dtable [vocab][E] is accumulated into; rows == padding_idx get
+ * nothing; tokens outside [0, vocab) write nothing and set *err (optional device int) to 1, where the reference's
+ * nn.Embedding raises IndexError */
 MMSA_API int mmsa_text_bwd(const float* dfeat, const float* feat, const int* arg, const float* emb,
                            const long long* ids, int nconv, const int* ksize_host, const int* feat_off_host,
                            const float* const* wp_host, float* const* dW_host, float* const* dbias_host, float* dtable,
-                           int B, int L, int E, int F, int ldf, long padding_idx, void* stream);
+                           int B, int L, int E, int F, int ldf, long padding_idx, long vocab, int* err, void* stream);
 
 /* ---- fusion head and classifiers: multimodal_model.py:202-225, :228-285, :365-404, :448-454. ---------------- */
 MMSA_API int mmsa_dense_fwd(const float* X, int ldx, const float* W, const float* bias, const float* gamma,

@@ -125,14 +125,14 @@ struct TextConvs {
 // Phase 1: the threads test the utterance's (conv, filter) pairs in parallel and compact the matching ones into
 // an LDS list (ballot + prefix count, so the list order is the pair order: deterministic).  Phase 2: thread c
 // walks the list four entries at a time, so four coalesced weight-row loads are in flight per step.
-// Rows of padding tokens are skipped; the finished row is added to the table gradient with float atomics
+// Rows of padding tokens and of tokens outside the vocabulary are skipped; the finished row is added to the table gradient with float atomics
 // (tokens repeated across the batch meet there).
 __global__ __launch_bounds__(256) void text_bwd_emb_kernel(const float* __restrict__ dfeat,
                                                            const float* __restrict__ feat,
                                                            const int* __restrict__ arg,
                                                            const long long* __restrict__ ids, TextConvs cv,
                                                            float* __restrict__ dtable, int L, int E, int F, int ldf,
-                                                           long padding_idx) {
+                                                           long padding_idx, long vocab, int* __restrict__ err) {
   extern __shared__ float sm[];
   const int nf = cv.nconv * F;
   float* lg = sm;                                       // [nf + 4] gradient of the matching pair
@@ -142,6 +142,10 @@ __global__ __launch_bounds__(256) void text_bwd_emb_kernel(const float* __restri
   const int t = blockIdx.x, b = blockIdx.y;
   const long long id = ids[(long)b * L + t];
   if (id == padding_idx) return;                        // uniform: the whole block leaves
+  if (id < 0 || id >= vocab) {                          // no row of the table belongs to this token: write nothing
+    if (threadIdx.x == 0 && err) *err = 1;
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int count = 0;
   for (int base = 0; base < nf; base += 256) {
@@ -245,12 +249,13 @@ MMSA_EXPORT int mmsa_bias_relu_maxtime_multi(const float* const* y, const float*
 
 // Backward of the whole text branch.  dfeat/feat/arg: [B][ldf] with conv i's filters at columns feat_off[i]..+F.
 // emb: gathered rows [B][L][E].  wp[i]: forward-packed weights [k_i][F][E].  dW[i]: [F][E][k_i] (overwritten),
-// dbias[i]: [F] (overwritten).  dtable: [vocab][E], ACCUMULATED into (caller zeroes it).
+// dbias[i]: [F] (overwritten).  dtable: [vocab][E], ACCUMULATED into (caller zeroes it).  A token id outside
+// [0, vocab) has no row: its gradient is dropped and *err (optional) is set to 1.
 MMSA_EXPORT int mmsa_text_bwd(const float* dfeat, const float* feat, const int* arg, const float* emb,
                               const long long* ids, int nconv, const int* ksize, const int* feat_off,
                               const float* const* wp, float* const* dW, float* const* dbias, float* dtable, int B, int L,
-                              int E, int F, int ldf, long padding_idx, void* stream) {
-  MMSA_REQUIRE(dfeat && feat && arg && emb && ids && ksize && feat_off && wp && dW && dbias && dtable);
+                              int E, int F, int ldf, long padding_idx, long vocab, int* err, void* stream) {
+  MMSA_REQUIRE(dfeat && feat && arg && emb && ids && ksize && feat_off && wp && dW && dbias && dtable && vocab > 0);
   MMSA_REQUIRE(nconv >= 1 && nconv <= 4 && B > 0 && B <= 65535 && L > 0 && E > 0 && E <= 1024 && E % 64 == 0 && F > 0);
   hipStream_t s = mmsa_stream(stream);
   TextConvs cv;
@@ -279,6 +284,6 @@ MMSA_EXPORT int mmsa_text_bwd(const float* dfeat, const float* feat, const int* 
   const size_t shmem = (size_t)3 * (nconv * F + 4) * sizeof(float);
   MMSA_REQUIRE(shmem <= 48 * 1024);
   hipLaunchKernelGGL(text_bwd_emb_kernel, dim3(L, B), dim3(256), shmem, s, dfeat, feat, arg, ids, cv, dtable, L, E, F,
-                     ldf, padding_idx);
+                     ldf, padding_idx, vocab, err);
   return mmsa_launch_status();
 }

@@ -212,8 +212,9 @@ class AudioTransform:
         out = torch.zeros_like(audio)
         n = audio.shape[1]
         if shift == 0:
-            # the reference's slices (`audio[:, :-0]`) are empty for a zero shift: the result is all zeros
-            return out
+            # the reference's slice assignment (`audio_shift[:, 0:] = audio[:, :-0]`, preprocess.py:65,70) has an empty
+            # right-hand side for a zero shift and raises; its __call__ answers with an all-zero map and draws no more
+            raise RuntimeError("time shift of zero samples: the reference's slice assignment fails for it")
         if right:
             out[:, shift:] = audio[:, :n - shift]
         else:

@@ -120,6 +120,7 @@ class _BranchFn(torch.autograd.Function):
             feat, st = audio_engine.audio_forward(module, inp, module.training, True, ws)
         else:
             feat, st = text_engine.text_forward(module, inp, True, ws)
+            text_engine.check_ids(st.err)
         ctx.module, ctx.st, ctx.ws, ctx.training = module, st, ws, module.training
         ctx.set_materialize_grads(False)
         return feat.clone()
@@ -199,7 +200,8 @@ class TextModel(nn.Module):
         if _needs_grad(self):
             return _BranchFn.apply(self, input_ids, *self.parameters())
         ws = self.__dict__.setdefault("_ws", Workspace(dev))
-        feat, _ = text_engine.text_forward(self, input_ids, False, ws)
+        feat, st = text_engine.text_forward(self, input_ids, False, ws)
+        text_engine.check_ids(st.err)
         return feat.clone()
 
 
@@ -246,6 +248,8 @@ class _ModelFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, audio, input_ids, labels, drops, *params):
         run = model._run(audio, input_ids, labels, drops, need_grad=True, ws=Workspace(params[0].device, False))
+        if run.text is not None:
+            text_engine.check_ids(run.text.err)
         ctx.model, ctx.run = model, run
         ctx.set_materialize_grads(False)
         loss = run.loss.view(()).clone() if run.loss is not None else None
@@ -489,7 +493,9 @@ class MultimodalSentimentModel(nn.Module):
             i1 = min(B, i0 + chunk)
             a = audio[i0:i1] if audio is not None and self.modality != "text" else None
             t = input_ids[i0:i1] if input_ids is not None and self.modality != "audio" else None
-            self._run(a, t, None, drops, need_grad=False, ws=ws, logits_out=logits[i0:i1])
+            run = self._run(a, t, None, drops, need_grad=False, ws=ws, logits_out=logits[i0:i1])
+        if run.text is not None:
+            text_engine.check_ids(run.text.err)      # the flag is sticky across the chunks
         probs = torch.empty_like(logits)
         loss = None
         ce = torch.empty(1, dtype=torch.float32, device=logits.device) if labels is not None else None

@@ -524,7 +524,7 @@ def bias_relu_maxtime_multi(ys, biases, louts, feat, arg, B, L, F):
               _iarr(louts), n, _chk(feat), _chk(arg, torch.int32), B, L, F, n * F, _stream())
 
 
-def text_bwd(dfeat, feat, arg, emb, ids, ksizes, wps, dWs, dbs, dtable, B, L, E, F, padding_idx=0):
+def text_bwd(dfeat, feat, arg, emb, ids, ksizes, wps, dWs, dbs, dtable, B, L, E, F, padding_idx=0, err=None):
     n = len(ksizes)
     ldf = n * F
     if dfeat.shape != (B, ldf) or feat.shape != (B, ldf) or arg.shape != (B, ldf) or emb.numel() != B * L * E:
@@ -532,10 +532,12 @@ def text_bwd(dfeat, feat, arg, emb, ids, ksizes, wps, dWs, dbs, dtable, B, L, E,
     for k, wp, dW, db in zip(ksizes, wps, dWs, dbs):
         if wp.numel() != k * F * E or dW.numel() != k * F * E or db.numel() != F:
             raise ValueError("text_bwd: bad weight sizes")
+    if dtable.dim() != 2 or dtable.shape[1] != E:
+        raise ValueError("text_bwd: dtable must be [vocab, E]")
     _lib.call("mmsa_text_bwd", _chk(dfeat), _chk(feat), _chk(arg, torch.int32), _chk(emb),
               _chk(ids, torch.int64), n, _iarr(ksizes), _iarr([i * F for i in range(n)]),
               _parr([_chk(w) for w in wps]), _parr([_chk(w) for w in dWs]), _parr([_chk(w) for w in dbs]),
-              _chk(dtable), B, L, E, F, ldf, padding_idx, _stream())
+              _chk(dtable), B, L, E, F, ldf, padding_idx, dtable.shape[0], _opt(err, torch.int32), _stream())
 
 
 # ---------------------------------------------------------------------------------------------- dense head

@@ -19,6 +19,21 @@ def world_info(group=None) -> Tuple[int, int]:
     return 0, 1
 
 
+def assert_same_on_all_ranks(blob: torch.Tensor, what: str, group=None, device=None):
+    """Raises on every rank unless the byte tensor ``blob`` is identical on all ranks (compared through a 3-word
+    digest: length, sum, position-weighted sum; one small collective, meant for set-up time)."""
+    b = blob.flatten().to(torch.int64)
+    w = torch.arange(1, b.numel() + 1, dtype=torch.int64) % 65521
+    digest = torch.stack([torch.tensor(b.numel()), b.sum(), (b * w).sum()]).to(torch.int64)
+    if device is not None:
+        digest = digest.to(device)
+    lo, hi = digest.clone(), digest.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not torch.equal(lo.cpu(), hi.cpu()):
+        raise RuntimeError(f"data-parallel ranks disagree on {what}")
+
+
 def make_buckets(n: int, bucket_elems: int) -> List[Tuple[int, int]]:
     """Contiguous [lo, hi) slices of a flat buffer of n elements, each at most bucket_elems long."""
     bucket_elems = max(int(bucket_elems), 1)

@@ -30,7 +30,9 @@ def text_forward(m, input_ids: torch.Tensor, need_grad: bool, ws: Workspace):
         raise NotImplementedError("HIP text branch supports filter sizes 2..7 and sequences at least that long")
     st = SimpleNamespace(B=B, L=L, E=E, F=F, ksizes=ksizes, ids=ids)
     st.emb = ws.buf("text.emb", (B, L, E))
-    st.err = ws.buf("text.err", 1, torch.int32)
+    # sticky flag: set by the gather / the backward scatter when a token id has no row in the table (a persistent
+    # workspace creates it zeroed once; check_ids reads and clears it)
+    st.err = ws.buf("text.err", 1, torch.int32, zero=not ws.persistent)
     ops.embedding_gather(ids, table, st.emb, st.err)
     n = len(ksizes)
     st.feat = ws.buf("text.feat", (B, n * F))
@@ -56,6 +58,20 @@ def text_forward(m, input_ids: torch.Tensor, need_grad: bool, ws: Workspace):
     return st.feat, st
 
 
+def check_ids(err: torch.Tensor):
+    """Raises what ``nn.Embedding`` raises in the reference (multimodal_model.py:179) when a token id was outside
+    the table.  Reads one int from the device (synchronises)."""
+    if int(err.item()):
+        err.zero_()
+        raise IndexError("index out of range in self")
+
+
+def check_ids_host(input_ids: torch.Tensor, vocab: int):
+    """The same check for token ids that are still in host memory (no device round trip)."""
+    if input_ids.numel() and (int(input_ids.min()) < 0 or int(input_ids.max()) >= vocab):
+        raise IndexError("index out of range in self")
+
+
 def text_backward(m, st, dfeat: torch.Tensor, grads: Grads):
     table = m.embedding.weight
     dtable = grads.of(table)
@@ -63,4 +79,5 @@ def text_backward(m, st, dfeat: torch.Tensor, grads: Grads):
         dtable.zero_()    # the kernel scatter-adds token rows into it
     ops.text_bwd(dfeat.contiguous(), st.feat, st.arg, st.emb, st.ids, st.ksizes, st.wps,
                  [grads.of(c.weight) for c in m.convs], [grads.of(c.bias) for c in m.convs], dtable,
-                 st.B, st.L, st.E, st.F, padding_idx=m.embedding.padding_idx if m.embedding.padding_idx is not None else -1)
+                 st.B, st.L, st.E, st.F, padding_idx=m.embedding.padding_idx if m.embedding.padding_idx is not None else -1,
+                 err=st.err)

@@ -22,7 +22,7 @@ from typing import Optional
 
 import torch
 
-from . import ops, parallel
+from . import ops, parallel, text as text_engine
 from .audio import fork
 from .model import L2_LAMBDA, MultimodalSentimentModel
 from .workspace import Grads, Workspace
@@ -56,6 +56,8 @@ class TrainStep:
         self._pversion = None
         self._static = {}
         self._warm = 0
+        self._nstep = 0
+        self._replays = 0
         self.loss = None
         self.logits = None
         self.world = 1
@@ -66,6 +68,21 @@ class TrainStep:
         self.dist = distributed and torch.distributed.is_available() and torch.distributed.is_initialized()
         if self.dist:
             self.world = torch.distributed.get_world_size(process_group)
+            import mmsa_amd
+            if use_graph and not mmsa_amd.GRAPH_CHAIN_OK:
+                # the multi-rank step replays a chain of graphs with the collectives between them, which is only
+                # safe with the runtime's pre-recorded graph packets switched off (see mmsa_amd/__init__.py)
+                import warnings
+                warnings.warn("DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not in effect when the GPU was initialised: the "
+                              "multi-rank step launches its kernels eagerly instead of replaying a chain of graphs "
+                              "(export the variable before starting the process to get graph replay)")
+                self.use_graph = use_graph = False
+            if self.world > 1 and model.modality == "both":
+                # one modality-dropout decision per GLOBAL batch, as the reference makes one per batch
+                # (multimodal_model.py:264-268): every rank draws from torch's host generator, so the generators must
+                # be in the same state on all ranks (same seed, same construction sequence)
+                parallel.assert_same_on_all_ranks(torch.get_rng_state(), "torch's host RNG state (seed every rank "
+                                                  "identically before building the model)", process_group, dev)
         bucket = int(bucket_mb * 1024 * 1024 / 4)
         self._buckets = parallel.make_buckets(self.g.numel(), bucket)
         # overlapped exchange: [split, end) = text branch + head (ready early), [0, split) = audio branch
@@ -196,6 +213,15 @@ class TrainStep:
         if model.modality == "audio":
             ins["input_ids"] = None
         model._check_inputs(ins["audio"] if ins["wave"] is None else ins["wave"], ins["input_ids"])
+        # a token id outside the embedding table raises IndexError in the reference.  Ids that arrive in host memory
+        # are checked here; device-resident ids are checked by the kernels (they skip such tokens and raise a sticky
+        # flag), which check_ids() reads: after the first step and every CHECK_EVERY steps, so no step waits for it
+        self._nstep += 1
+        if ins["input_ids"] is not None:
+            if not ins["input_ids"].is_cuda:
+                text_engine.check_ids_host(ins["input_ids"], model.text_model.embedding.num_embeddings)
+            elif self._nstep == 2 or self._nstep % self.CHECK_EVERY == 0:
+                self.check_ids()
         for k, t in ins.items():
             if t is not None:
                 want = torch.int64 if k in ("input_ids", "labels") else torch.float32
@@ -261,7 +287,23 @@ class TrainStep:
         elif g2 is not None:
             self._allreduce()
             g2.replay()
+        if g2 is not None and self._replays < 3:
+            # a chain of graphs: make sure the first replays produced numbers (costs three synchronisations in total)
+            self._replays += 1
+            vals = self.state[4:5].isfinite() & self.loss.isfinite().all()
+            if not bool(vals.item()):
+                raise RuntimeError("replaying the multi-rank step as a chain of HIP graphs produced a non-finite loss or "
+                                   "gradient norm; DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be in the environment before "
+                                   "the process first touches the GPU")
         return self.loss
+
+    CHECK_EVERY = 256
+
+    def check_ids(self):
+        """Raises IndexError if any step since the last call saw a token id outside the embedding table (those
+        tokens contributed zero rows and no gradient).  Synchronises."""
+        if self.model.text_model is not None:
+            text_engine.check_ids(self.ws.buf("text.err", 1, torch.int32))
 
     @torch.no_grad()
     def grad_norm(self) -> torch.Tensor:

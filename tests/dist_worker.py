@@ -1,4 +1,4 @@
-"""Helper process of test_gpu_train.py::test_two_ranks_sharing_one_gpu: one data-parallel rank.
+"""Helper process of test_zy_two_ranks.py::test_two_ranks_sharing_one_gpu: one data-parallel rank.
 
 usage: python dist_worker.py RANK WORLD PORT OUT_PREFIX USE_GRAPH
 Every rank uses cuda:0 (the test box has one GPU) and the gloo backend, which accepts GPU tensors; what is under
@@ -63,9 +63,11 @@ def main():
                 print(f"rank {rank} watchdog: " + ", ".join(f"{k} gpu-reached={v.query()}" for k, v in marks.items()),
                       file=trace, flush=True)
         threading.Thread(target=watchdog, daemon=True).start()
-    for s in range(4):
+    for s in range(6):
         b = batch_tensors(100 * s + 8 * rank, 8, vocab=SMALL_VOCAB, device="cuda")
         losses.append(float(ts.step(audio=b["audio"], input_ids=b["input_ids"], labels=b["label"])))
+        gn = float(ts.grad_norm())
+        assert losses[-1] == losses[-1] and abs(losses[-1]) < 1e3 and gn == gn and 0.0 < gn < 1e6, (s, losses[-1], gn)
         print(f"rank {rank} step {s} loss {losses[-1]:.5f}", file=trace, flush=True)
     torch.cuda.synchronize()
     torch.save({"flat": m._arena.flat.cpu(), "losses": losses}, f"{prefix}.rank{rank}.pt")

@@ -176,3 +176,43 @@ def test_noise_gate_plan_constants_and_oracle_behaviour():
     whole = denoise_ref.reduce_noise(y, 22050)
     parts = denoise_ref.reduce_noise(y, 22050, chunk_size=20000, padding=15000)
     assert np.isfinite(parts).all() and np.abs(whole - parts).max() < 0.3 * np.abs(whole).max()
+
+
+def test_mel_filterbank_against_an_independent_htk_implementation():
+    """transformers.audio_utils.mel_filter_bank(norm=None, mel_scale="htk") is a second, independently written HTK
+    filterbank (float64 numpy).  It pins nothing -- the reference calls torchaudio -- but two implementations of the
+    same published formula must agree to float32 rounding of the triangle edges."""
+    au = pytest.importorskip("transformers.audio_utils")
+    from oracle import frontend_ref
+    other = au.mel_filter_bank(num_frequency_bins=513, num_mel_filters=64, min_frequency=0.0, max_frequency=11025.0,
+                               sampling_rate=22050, norm=None, mel_scale="htk")
+    ours = frontend_ref.mel_filterbank().numpy()
+    assert other.shape == ours.shape == (513, 64)
+    assert np.abs(other - ours).max() < 2e-5
+    ours64 = frontend_ref.mel_filterbank(dtype=__import__("torch").float64).numpy()
+    assert np.abs(other - ours64).max() < 1e-9
+    # same support except where a triangle's corner falls within rounding distance of an FFT bin
+    assert int(((other > 0) != (ours > 0)).sum()) <= 2
+
+
+def test_zero_time_shift_raises_and_stops_drawing(monkeypatch):
+    """preprocess.py:65,70: `audio_shift[:, 0:] = audio[:, :-0]` raises for a zero shift; __call__ (`:172-174`) then
+    returns zeros without consuming further random numbers.  The host-side path must do the same."""
+    import random
+    import torch
+    from mmsa_amd.frontend import AudioTransform
+    seq = iter([0.9, 0.0, 0.7, 0.9, 0.9, 0.9])     # shift branch taken, shift fraction 0 -> zero samples, direction
+    calls = []
+
+    def fake():
+        calls.append(1)
+        return next(seq)
+    monkeypatch.setattr(random, "random", fake)
+    t = AudioTransform(augment=True, device="cpu", waveform_only=True, noise_reduce=False)
+    wave = torch.randn(1, 30000)
+    out = t(wave, 22050)
+    assert out.shape == (1, 66150) and float(out.abs().max()) == 0.0
+    assert len(calls) == 3                          # no draw for the noise or the index-resampling decision
+    seq = iter([0.9, 0.0, 0.7])
+    with pytest.raises(RuntimeError):
+        AudioTransform(augment=True, device="cpu", waveform_only=True, noise_reduce=False, strict=True)(wave, 22050)

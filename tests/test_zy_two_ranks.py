@@ -1,0 +1,73 @@
+"""Two data-parallel ranks on one GPU (collected late: the file name sorts behind the single-process GPU tests).
+
+The worker processes (tests/dist_worker.py) run the multi-rank step of mmsa_amd.trainer.TrainStep -- split backward,
+asynchronous gradient exchanges, clip on the reduced gradient, and in graph mode the chain of three graphs with the
+collectives between them -- with gloo over GPU tensors, because a test box has one GPU and RCCL wants one GPU per rank.
+A stuck rank reports where it waits and exits non-zero (faulthandler), the parent gives up after 150 s."""
+import os
+
+import pytest
+import torch
+
+from conftest import SMALL_VOCAB, batch_tensors, model_inputs, seeded_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("use_graph", ["0", "1"])
+def test_two_ranks_sharing_one_gpu(use_graph, tmp_path):
+    """Two data-parallel ranks (gloo over GPU tensors, both on this GPU) against a single-process emulation: per step
+    the gradient is the mean of the two ranks' autograd gradients (each already holds the regulariser's gradient
+    once), clipped at 1.0 and applied by torch.optim.AdamW.  Replicas must stay bit-identical to each other."""
+    import subprocess
+    import sys
+    port = str(29800 + (os.getpid() % 150))
+    prefix = str(tmp_path / "dp")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, prefix, use_graph],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=150)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    traces = ""
+    for r in range(2):
+        path = f"{prefix}.rank{r}.trace"
+        if os.path.exists(path):
+            traces += f"--- rank {r}\n" + open(path).read()[-3000:]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs) + traces
+    r0 = torch.load(prefix + ".rank0.pt", weights_only=True)
+    r1 = torch.load(prefix + ".rank1.pt", weights_only=True)
+    assert torch.equal(r0["flat"], r1["flat"])
+
+    m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+    m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-4)
+    params = list(m.parameters())
+    for s in range(6):
+        acc, ls = None, []
+        for rank in range(2):
+            b = batch_tensors(100 * s + 8 * rank, 8, vocab=SMALL_VOCAB, device=DEV)
+            opt.zero_grad()
+            out = m(**model_inputs("both", b), labels=b["label"])
+            out["loss"].backward()
+            ls.append(float(out["loss"].detach()))
+            g = [p.grad.detach().clone() for p in params]
+            acc = g if acc is None else [a + x for a, x in zip(acc, g)]
+        for p, a in zip(params, acc):
+            p.grad = a / 2
+        torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
+        opt.step()
+        assert abs(ls[0] - r0["losses"][s]) < 2e-4 and abs(ls[1] - r1["losses"][s]) < 2e-4, (s, ls, r0["losses"][s])
+    got = m._arena.views_of(r0["flat"].to(DEV))
+    for (k, pa), pb in zip(m.named_parameters(), got):
+        if "conv1.0.bias" in k:
+            continue
+        d = float(torch.linalg.vector_norm(pa.detach() - pb))
+        assert d < 0.05 * 6e-3 * pa.numel() ** 0.5 + 1e-6, k
