@@ -40,11 +40,43 @@ def make_buckets(n: int, bucket_elems: int) -> List[Tuple[int, int]]:
     return [(i, min(n, i + bucket_elems)) for i in range(0, n, bucket_elems)]
 
 
+class _HostStagedSum:
+    """Sum of a GPU tensor over a process group whose transport works on host memory (gloo).
+
+    gloo accepts GPU tensors, but its own staging (an event on the compute stream, a high-priority pool stream that
+    waits for it and copies to pinned memory, a worker thread that synchronises that stream) was seen never to be
+    released when the compute stream's last submission was a HIP graph launch of the training step: the compute
+    stream's work did not complete until the process was killed -- in a single process as well, with or without
+    asynchronous handles, with the graph runtime's pre-recorded packets on or off.  The same step over RCCL, and
+    over gloo with the staging below, runs.  So the staging is done here, on the compute stream itself: copy to
+    pinned memory behind the producer, and at ``wait()`` block the host on that copy, reduce the host buffer, copy it
+    back in stream order."""
+
+    def __init__(self, dst: torch.Tensor, group):
+        self.dst, self.group = dst, group
+        self.host = torch.empty(dst.shape, dtype=dst.dtype, pin_memory=True)
+        self.host.copy_(dst, non_blocking=True)
+        self.copied = torch.cuda.Event()
+        self.copied.record()
+
+    def wait(self):
+        self.copied.synchronize()
+        dist.all_reduce(self.host, op=dist.ReduceOp.SUM, group=self.group)
+        self.dst.copy_(self.host, non_blocking=True)
+        return True
+
+
 def allreduce_buckets(flat: torch.Tensor, buckets, group=None, async_op: bool = False):
     """Sum ``flat`` over ranks, one all-reduce per bucket (in place).  Returns the work handles when async."""
+    staged = flat.is_cuda and dist.get_backend(group) == "gloo"
     handles = []
     for lo, hi in buckets:
-        h = dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if staged:
+            h = _HostStagedSum(flat[lo:hi], group)
+            if not async_op:
+                h.wait()
+        else:
+            h = dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         if async_op:
             handles.append(h)
     return handles

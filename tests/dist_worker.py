@@ -1,9 +1,10 @@
 """Helper process of test_zy_two_ranks.py::test_two_ranks_sharing_one_gpu: one data-parallel rank.
 
 usage: python dist_worker.py RANK WORLD PORT OUT_PREFIX USE_GRAPH
-Every rank uses cuda:0 (the test box has one GPU) and the gloo backend, which accepts GPU tensors; what is under
-test is the host logic of the multi-rank step (split backward, asynchronous exchanges, clip on the reduced gradient),
-not the transport."""
+Every rank uses cuda:0 (the test box has one GPU; RCCL wants one GPU per rank) and the gloo backend, for which
+mmsa_amd.parallel stages the gradient buckets through pinned host memory; what is under test is the host logic of the
+multi-rank step (split backward, exchanges issued early and waited for late, clip on the reduced gradient, the
+chain of graphs), not the transport."""
 import os
 import sys
 
