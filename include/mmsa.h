@@ -13,7 +13,8 @@
  *   - `stream` is a hipStream_t (0 = default stream); kernels are only enqueued, never synchronised;
  *   - return value: 0 on success, MMSA_ERR_ARG (-1) for rejected arguments (nothing was launched),
  *     MMSA_ERR_LAUNCH (-2) if HIP reported a launch error;
- *   - the library allocates no device memory: scratch comes from the caller, sized by the *_floats helpers;
+ *   - the library allocates no device memory: scratch comes from the caller, sized by the *_floats helpers
+ *     (one entry point, mmsa_ln_scale_bwd_static, keeps its scratch in a device array inside the library instead);
  *   - entry points are stateless and re-entrant; two calls that share output or scratch buffers must be ordered
  *     by the caller (same stream).
  */
@@ -222,7 +223,15 @@ MMSA_API int mmsa_ln_scale_fwd(const float* x, const float* gamma, const float* 
 MMSA_API int mmsa_ln_scale_bwd(const float* dy, int ldy, const float* x, const float* gamma, const float* beta,
                                const float* scale, const float* keep, const float* stats, float* dx, float* dgamma,
                                float* dbeta, float* dscale, float* scratch, int B, int N, void* stream);
-/* (w0,w1) = softmax(att[b]); fused = P[:, :Hd]*w0 + P[:, Hd:]*w1   (:275-283) */
+/* mmsa_ln_scale_bwd without the scratch argument.  No counterpart in the reference: it exists for callers that can
+ * neither allocate device memory nor carry a workspace (code under HIP graph capture, tight serving / training
+ * loops, harnesses that forbid hipMalloc).  The scratch is a 4 MiB device array inside the library, one copy per GPU;
+ * the call allocates nothing.  B*N + B must not exceed 1 048 576 floats (MMSA_ERR_LIMIT otherwise, nothing launched).
+ * The device that owns `stream` must be the current device.  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU (different streams without ordering) race.  Results are bit-identical to mmsa_ln_scale_bwd. */
+MMSA_API int mmsa_ln_scale_bwd_static(const float* dy, int ldy, const float* x, const float* gamma, const float* beta,
+                                      const float* scale, const float* keep, const float* stats, float* dx,
+                                      float* dgamma, float* dbeta, float* dscale, int B, int N, void* stream);
 /* ---- fused fusion head of the 'both' model: multimodal_model.py:216-225 (normaliser), :263-285 (fusion),
  *      :393-404 (classifier).  One workgroup per utterance carries the row through every layer.
  * ptrs_host: host array of mmsa_head_both_slots() device pointers (float unless noted), in this order:

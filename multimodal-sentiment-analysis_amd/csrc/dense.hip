@@ -8,6 +8,8 @@
 // stream from L2, every wave reduces along K with lanes on consecutive k (coalesced weight rows).
 #include "mmsa_common.h"
 
+#include <mutex>
+
 namespace {
 
 enum Epilogue {
@@ -591,6 +593,53 @@ MMSA_EXPORT int mmsa_ln_scale_bwd(const float* dy, int ldy, const float* x, cons
                                   float* dbeta, float* dscale, float* scratch, int B, int N, void* stream) {
   MMSA_REQUIRE(dy && x && gamma && beta && scale && stats && dx && dgamma && dbeta && dscale && scratch);
   MMSA_REQUIRE(B > 0 && N > 0 && ldy >= N);
+  hipStream_t s = mmsa_stream(stream);
+  float* dLn = scratch;
+  float* part = scratch + (long)B * N;
+  hipLaunchKernelGGL(ln_scale_bwd_kernel, dim3(B), dim3(256), 0, s, dy, ldy, x, gamma, beta, scale, keep, stats, dx, dLn,
+                     part, N);
+  hipLaunchKernelGGL(ln_scale_bwd_params_kernel, dim3(mmsa_cdiv(N, 256)), dim3(256), 0, s, dLn, x, stats, part, dgamma,
+                     dbeta, dscale, B, N);
+  return mmsa_launch_status();
+}
+
+// ---- the same backward for callers that cannot allocate or bring a workspace -------------------------------------
+// The scratch of mmsa_ln_scale_bwd (dLn [B][N], then B partial sums) lives in a file-scope device array.  Each GPU
+// holds its own copy of that array at its own address: the address is looked up once per device (with that device
+// current) and kept; host code never uses the array's name as an address.  Every call on one GPU shares that GPU's
+// array, so calls that overlap on one GPU race; nothing in it has to start at zero (every element read by the second
+// kernel is written by the first one of the same call).
+#define MMSA_LN_STATIC_FLOATS (1 << 20)
+static __device__ __align__(256) float ln_static_scratch[MMSA_LN_STATIC_FLOATS];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_static_mu;
+float* g_static_ptr[kMaxDevices] = {};
+
+// device-side address of ln_static_scratch on the current device (nullptr on failure)
+float* static_scratch_of_current_device() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lock(g_static_mu);
+  if (!g_static_ptr[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(ln_static_scratch)) != hipSuccess || !p) return nullptr;
+    g_static_ptr[dev] = static_cast<float*>(p);
+  }
+  return g_static_ptr[dev];
+}
+}  // namespace
+
+MMSA_EXPORT int mmsa_ln_scale_bwd_static(const float* dy, int ldy, const float* x, const float* gamma,
+                                         const float* beta, const float* scale, const float* keep,
+                                         const float* stats, float* dx, float* dgamma, float* dbeta, float* dscale,
+                                         int B, int N, void* stream) {
+  MMSA_REQUIRE(dy && x && gamma && beta && scale && stats && dx && dgamma && dbeta && dscale);
+  MMSA_REQUIRE(B > 0 && N > 0 && ldy >= N);
+  if ((long)B * N + B > (long)MMSA_LN_STATIC_FLOATS) return MMSA_ERR_LIMIT;
+  float* scratch = static_scratch_of_current_device();
+  if (!scratch) return MMSA_ERR_LAUNCH;
   hipStream_t s = mmsa_stream(stream);
   float* dLn = scratch;
   float* part = scratch + (long)B * N;
