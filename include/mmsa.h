@@ -138,6 +138,20 @@ MMSA_API int mmsa_conv_wgrad_reduce(const float* workspace, float* dW, int B, in
 MMSA_API int mmsa_conv_wgrad_pair(const float* X, const float* dY9, const float* dY1, float* ws9, float* ws1,
                                   float* dW9, float* dW1, int B, int H, int W, int Cin, int Cout, const int* dh_host,
                                   const int* dw_host, void* stream);
+/* The same gradients by the second-generation kernel (one workgroup per CU, operands streamed into LDS by DMA under
+ * the matrix work): mmsa_conv_wgrad_slabs writes *nslabs_host partial slabs [9][Cin][Cout] (and, when dY_sc is given,
+ * as many [Cin][Cout] slabs of the 1x1 shortcut that reads the same X; multimodal_model.py:56-59) as sized by
+ * mmsa_conv_wgrad_slab_floats (returns the floats of the 3x3 slabs; MMSA_ERR_LIMIT if a strip of the map does not fit
+ * in LDS); mmsa_conv_wgrad_reduce_multi sums the slabs of any number of layers into dW[Cout][Cin][ntaps] in one launch
+ * (fixed order).  descs_device: n records {const float* slabs; float* dW; int nslabs, ntaps, Cin, Cout, block0,
+ * nblocks} of mmsa_conv_wgrad_reduce_desc_bytes() bytes, nblocks = ceil(ntaps*Cin*Cout/256), block0 = sum of the
+ * earlier nblocks, total_blocks = sum of all. */
+MMSA_API long mmsa_conv_wgrad_slab_floats(int B, int H, int W, int Cin, int Cout, int with_shortcut, int* nslabs_host);
+MMSA_API int mmsa_conv_wgrad_slabs(const float* X, const float* dY, const float* dY_sc, float* slabs, float* slabs_sc,
+                                   int B, int H, int W, int Cin, int Cout, const int* dh_host, const int* dw_host,
+                                   void* stream);
+MMSA_API int mmsa_conv_wgrad_reduce_desc_bytes(void);
+MMSA_API int mmsa_conv_wgrad_reduce_multi(const void* descs_device, int n, int total_blocks, void* stream);
 
 /* ---- audio branch, bandwidth-bound parts: multimodal_model.py:78-83 (stem), :27-42 (SEBlock), :64-70
  *      (ResidualBlock tail), :87-96,118-127 (pools, global average). ----------------------------------------- */

@@ -22,6 +22,17 @@ FORK_WGRAD = _os.environ.get("MMSA_FORK_WGRAD", "1") != "0"
 FORK_ANY = _os.environ.get("MMSA_FORK", "1") != "0"     # 0: the whole step on one stream (diagnostics)
 # 1: a block's first 3x3 convolution and its 1x1 shortcut share one launch (and one BatchNorm coefficient launch)
 FWD_PAIR = _os.environ.get("MMSA_FWD_PAIR", "1") != "0"
+# Weight-gradient kernels: "old" (default) = the first generation (two 256-thread workgroups per CU, one reduction
+# launch per layer); "slabs" = the DMA-fed second generation (one 512-thread workgroup per CU, all layers' partial slabs
+# summed by one launch at the end of the backward pass).  Alone, the second generation is faster on every layer
+# (50 vs 71 us with its reduction on the 256 -> 256 layer at batch 32); inside the step it loses: the helper stream's
+# kernels run beside the data-gradient chain, and a kernel that takes all of a CU's LDS and registers displaces that
+# chain's kernels instead of filling its gaps (batch 32, one GPU: 1.44 ms against 1.41 ms per step).
+WGRAD = _os.environ.get("MMSA_WGRAD", "old")
+# 1: every weight-gradient launch waits until the last data-gradient convolution has been launched, then the whole
+# chain runs beside the stem's backward.  0 (default): each launch from its own fork point, as early as its inputs
+# exist (measured: 1.41 vs 1.59 ms per step with the first-generation kernels, 1.44 vs 1.51 with the second).
+WGRAD_DEFER = _os.environ.get("MMSA_WGRAD_DEFER", "0") != "0"
 
 
 def side_stream(device, which: int = 0) -> torch.cuda.Stream:
@@ -168,7 +179,8 @@ def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: 
     return s
 
 
-def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx: bool):
+def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx: bool, reduce_list=None,
+                   deferred=None):
     """d_out: [B,H/2,W/2,Cout] -> gradient w.r.t. the block input [B,H,W,Cin] (or None).
 
     The three weight gradients (and the squeeze-excite ones) feed nothing but the optimiser: they run on a helper
@@ -182,25 +194,45 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
     ops.resblock_bwd_ew(d_out, s.c2, s.sc, s.coeff2, s.coeffs, s.gate, s.hid, s.gap, s.bsum2, W1, W2, d_c2, d_sc,
                         grads.of(bn2.weight), grads.of(bn2.bias), grads.of(bns.weight), grads.of(bns.bias),
                         None, None, scratch, B, H, W, Cout, training)
-    wsz = max(ops.conv_wgrad_workspace(B, H, W, Cout, Cout, 9), ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 9))
-    wg = ws.buf(name + ".wgrad_ws", wsz)
-    wgs = ws.buf(name + ".wgrad_ws_sc", ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 1))
     d_h1 = ws.buf(name + ".d_h1", (B, H, W, Cout))
     d_c1 = d_h1                                   # bn_relu_bwd works in place
     d_in = ws.buf(name + ".d_in", (B, H, W, Cin)) if need_dx else None
+    gw2, gw1, gws = grads.of(blk.conv2.weight), grads.of(blk.conv1.weight), grads.of(blk.shortcut[0].weight)
+    n2 = ops.conv_wgrad_slab_count(B, H, W, Cout, Cout, False) if WGRAD == "slabs" else 0
+    n1 = ops.conv_wgrad_slab_count(B, H, W, Cin, Cout, True) if WGRAD == "slabs" else 0
+    if n1 and n2:
+        sl2 = ws.buf(name + ".c2.slabs", (n2, 9, Cout, Cout))
+        sl1 = ws.buf(name + ".c1.slabs", (n1, 9, Cin, Cout))
+        sls = ws.buf(name + ".sc.slabs", (n1, Cin, Cout))
+        if reduce_list is None:
+            raise ValueError("block_backward: the slab path needs a reduce list")
+        reduce_list += [(sl2, gw2, n2, 9, Cout, Cout), (sl1, gw1, n1, 9, Cin, Cout), (sls, gws, n1, 1, Cin, Cout)]
 
-    def wgrad_conv2():                            # needs d_c2 (and the scratch of the elementwise backward)
-        ops.resblock_bwd_se_wgrad(scratch, s.hid, s.gap, grads.of(W1), grads.of(W2), B, H, W, Cout)
-        ops.conv_wgrad(s.h1, d_c2, grads.of(blk.conv2.weight), wg, B, H, W, Cout, Cout, ops.TAPS3X3)
+        def wgrad_conv2():                        # needs d_c2 (and the scratch of the elementwise backward)
+            ops.resblock_bwd_se_wgrad(scratch, s.hid, s.gap, grads.of(W1), grads.of(W2), B, H, W, Cout)
+            ops.conv_wgrad_slabs(s.h1, d_c2, None, sl2, None, B, H, W, Cout, Cout)
 
-    def wgrad_conv1_shortcut():                   # needs d_c1 and d_sc; both read the block input
-        ops.conv_wgrad_pair(s.a_in, d_c1, grads.of(blk.conv1.weight), d_sc, grads.of(blk.shortcut[0].weight), wg, wgs,
-                            B, H, W, Cin, Cout)
+        def wgrad_conv1_shortcut():               # needs d_c1 and d_sc; both read the block input
+            ops.conv_wgrad_slabs(s.a_in, d_c1, d_sc, sl1, sls, B, H, W, Cin, Cout)
+    else:
+        wsz = max(ops.conv_wgrad_workspace(B, H, W, Cout, Cout, 9), ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 9))
+        wg = ws.buf(name + ".wgrad_ws", wsz)
+        wgs = ws.buf(name + ".wgrad_ws_sc", ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 1))
+
+        def wgrad_conv2():
+            ops.resblock_bwd_se_wgrad(scratch, s.hid, s.gap, grads.of(W1), grads.of(W2), B, H, W, Cout)
+            ops.conv_wgrad(s.h1, d_c2, gw2, wg, B, H, W, Cout, Cout, ops.TAPS3X3)
+
+        def wgrad_conv1_shortcut():
+            ops.conv_wgrad_pair(s.a_in, d_c1, gw1, d_sc, gws, wg, wgs, B, H, W, Cin, Cout)
 
     f2 = fork(ws, d_out.device, enable=FORK_WGRAD).mark()           # d_c2 / d_sc are ready
     ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
-    with f2:
-        wgrad_conv2()
+    if deferred is not None:
+        deferred.append(wgrad_conv2)
+    else:
+        with f2:
+            wgrad_conv2()
     sc2 = ws.buf(name + ".bnrelu_scratch", ops.bn_relu_bwd_scratch(B * H * W, Cout))
     ops.bn_relu_bwd(d_h1, s.c1, s.coeff1, grads.of(blk.bn1.weight), grads.of(blk.bn1.bias), sc2, B * H * W, Cout,
                     training)
@@ -212,8 +244,11 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
             ops.conv_fwd_dual_split(d_c1, s.w1d, d_sc, s.wsd, d_in, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
         else:
             ops.conv_fwd_dual(d_c1, s.w1d, d_sc, s.wsd, d_in, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
-    with f1:
-        wgrad_conv1_shortcut()
+    if deferred is not None:
+        deferred.append(wgrad_conv1_shortcut)
+    else:
+        with f1:
+            wgrad_conv1_shortcut()
     return d_in
 
 
@@ -270,10 +305,26 @@ def audio_backward(m, st, dfeat: torch.Tensor, training: bool, grads: Grads, ws:
     B = st.B
     d = ws.buf("audio.d_last", (B, st.P, st.C))
     ops.gap_bwd(dfeat.contiguous(), d, B, st.P, st.C)
+    reduce_list = []
+    deferred = [] if WGRAD_DEFER and ws.persistent and FORK_WGRAD and FORK_ANY else None
     for blk, s in zip((m.res_block3, m.res_block2, m.res_block1), reversed(st.blocks)):
-        d = block_backward(blk, s, d, training, grads, ws, need_dx=True)
+        d = block_backward(blk, s, d, training, grads, ws, need_dx=True, reduce_list=reduce_list, deferred=deferred)
+    fw = fork(ws, dfeat.device).mark() if deferred else None     # the last data-gradient convolution is on its way
     conv0, bn0 = m.conv1[0], m.conv1[1]
     scratch = ws.buf("stem.bwd_scratch", ops.stem_bwd_scratch(B, st.H))
     ops.stem_bwd(st.x, conv0.weight, conv0.bias, st.coeff0, d, grads.of(conv0.weight), grads.of(conv0.bias),
                  grads.of(bn0.weight), grads.of(bn0.bias), scratch, B, st.H, st.W, training)
+    if deferred:
+        with fw:
+            for fn in deferred:
+                fn()
+    if reduce_list:
+        # every layer's partial slabs become gradients in one launch, behind the last weight-gradient kernel
+        plan = ws.objs.get("audio.reduceplan")
+        if plan is None:
+            plan = ops.ReducePlan()
+            if ws.persistent:
+                ws.objs["audio.reduceplan"] = plan
+        with fork(ws, dfeat.device, enable=FORK_WGRAD):
+            plan.run(reduce_list)
     fork(ws, dfeat.device).join()                # all weight gradients are in

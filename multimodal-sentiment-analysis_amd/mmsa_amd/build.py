@@ -10,7 +10,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(PKG_DIR), "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libmmsa_hip.so")
 OBJ_DIR = os.path.join(CSRC, "build")
-SOURCES = ("frontend.hip", "denoise.hip", "conv.hip", "audio_ew.hip", "text.hip", "dense.hip", "head.hip", "optim.hip")
+SOURCES = ("frontend.hip", "denoise.hip", "conv.hip", "wgrad.hip", "audio_ew.hip", "text.hip", "dense.hip", "head.hip", "optim.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall",
          "-Wno-unused-function"]
 

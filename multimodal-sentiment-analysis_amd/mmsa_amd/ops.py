@@ -353,6 +353,71 @@ def conv_wgrad_pair(X, dY9, dW9, dY1, dW1, ws9, ws1, B, H, W, Cin, Cout, taps=No
         ev.record()
 
 
+def conv_wgrad_slab_count(B, H, W, Cin, Cout, with_shortcut: bool) -> int:
+    """Partial slabs one launch of :func:`conv_wgrad_slabs` writes for this geometry; 0 if a strip of the map does not
+    fit in LDS (rows wider than about 290 positions), in which case the first-generation kernels serve."""
+    n = ctypes.c_int()
+    rc = _lib.load().mmsa_conv_wgrad_slab_floats(B, H, W, Cin, Cout, int(with_shortcut),
+                                                 ctypes.cast(ctypes.byref(n), ctypes.c_void_p))
+    if rc == -3:
+        return 0
+    if rc < 0:
+        raise _lib.MmsaError(f"mmsa_conv_wgrad_slab_floats rejected its arguments (status {rc})")
+    return n.value
+
+
+def conv_wgrad_slabs(X, dY, dY_sc, slabs, slabs_sc, B, H, W, Cin, Cout, taps=None):
+    """Partial sums of the 3x3 weight gradient (from dY) and, when dY_sc is given, of the 1x1 shortcut's (from dY_sc;
+    both convolutions read X): slabs [nslabs, 9, Cin, Cout], slabs_sc [nslabs, Cin, Cout].  :class:`ReducePlan` turns
+    slabs into gradients."""
+    taps = TAPS3X3 if taps is None else taps
+    n = B * H * W
+    if X.numel() != n * Cin or dY.numel() != n * Cout or len(taps) != 9 or (dY_sc is not None and dY_sc.numel() != n * Cout):
+        raise ValueError("conv_wgrad_slabs: operand sizes do not match the geometry")
+    ns = conv_wgrad_slab_count(B, H, W, Cin, Cout, dY_sc is not None)
+    if slabs.numel() < ns * 9 * Cin * Cout or (dY_sc is not None and (slabs_sc is None or slabs_sc.numel() < ns * Cin * Cout)):
+        raise ValueError("conv_wgrad_slabs: slab buffer too small")
+    kind = "conv_wgrad2_kernel<%s>" % ("true" if dY_sc is not None else "false")
+    ev = _prof_begin(kind, 2.0 * n * Cin * Cout * (10 if dY_sc is not None else 9))
+    _lib.call("mmsa_conv_wgrad_slabs", _chk(X), _chk(dY), _opt(dY_sc), _chk(slabs), _opt(slabs_sc), B, H, W, Cin, Cout,
+              _iarr([t[0] for t in taps]), _iarr([t[1] for t in taps]), _stream())
+    if ev is not None:
+        ev.record()
+    return ns
+
+
+class ReducePlan:
+    """A device-resident table of (slabs, dW, nslabs, ntaps, Cin, Cout) records: one launch sums the slabs of all of
+    them into the reference's [Cout][Cin][kh][kw] gradients.  The table is rebuilt only when an entry changes."""
+
+    def __init__(self):
+        self.key = None
+        self.table = None
+        self.n = 0
+        self.blocks = 0
+
+    def run(self, entries):
+        import numpy as np
+        key = tuple((s.data_ptr(), d.data_ptr(), int(ns), int(nt), int(ci), int(co)) for s, d, ns, nt, ci, co in entries)
+        if key != self.key:
+            dt = np.dtype([("slabs", "<u8"), ("dW", "<u8"), ("nslabs", "<i4"), ("ntaps", "<i4"), ("Cin", "<i4"),
+                           ("Cout", "<i4"), ("block0", "<i4"), ("nblocks", "<i4")])
+            if dt.itemsize != _lib.query("mmsa_conv_wgrad_reduce_desc_bytes"):
+                raise _lib.MmsaError("reduce descriptor layout mismatch")
+            arr = np.zeros(len(entries), dtype=dt)
+            b0 = 0
+            for i, (s, d, ns, nt, ci, co) in enumerate(entries):
+                _chk(s), _chk(d)
+                if d.numel() != nt * ci * co or s.numel() < ns * nt * ci * co or ns < 1:
+                    raise ValueError("ReducePlan: slab / gradient sizes do not match")
+                nb = (nt * ci * co + 255) // 256
+                arr[i] = (key[i][0], key[i][1], ns, nt, ci, co, b0, nb)
+                b0 += nb
+            self.table = torch.from_numpy(arr.view(np.uint8)).to(entries[0][0].device)
+            self.key, self.n, self.blocks = key, len(entries), b0
+        _lib.call("mmsa_conv_wgrad_reduce_multi", self.table.data_ptr(), self.n, self.blocks, _stream())
+
+
 # ---------------------------------------------------------------------------------------------- audio branch
 def stem_stats(x, w, bias, partial, B, H, W):
     if x.numel() != B * H * W or partial.numel() != B * H * 64 or w.numel() != 288 or bias.numel() != 32:

@@ -456,3 +456,42 @@ def test_split_k_dual_convolution_matches_the_unsplit_launch():
         outs.append(y)
     check(outs[0], ref, 1e-5)          # fp32 sums over K = 2560 in two associations
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,sc", [(3, 8, 16, 256, 256, False), (2, 8, 16, 128, 256, True),
+                                                 (3, 16, 32, 128, 128, False), (2, 16, 32, 64, 128, True),
+                                                 (3, 32, 65, 64, 64, False), (2, 32, 65, 32, 64, True),
+                                                 (1, 5, 7, 32, 64, True), (9, 3, 33, 64, 64, False)])
+def test_weight_gradient_slabs_match_float64(B, H, W, Cin, Cout, sc):
+    """The DMA-fed weight-gradient kernel + the multi-layer slab reduction against float64 autograd of F.conv2d, for
+    the six layer shapes of the model (shortcut riding along where the model has one) and two ragged geometries (odd
+    width, height that no strip height divides, fewer strips than workgroups)."""
+    from mmsa_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + W)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    dy = torch.randn(B, H, W, Cout, generator=g)
+    dy1 = torch.randn(B, H, W, Cout, generator=g) if sc else None
+    xd = x.permute(0, 3, 1, 2).double()
+    w9 = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xd, w9, padding=1).backward(dy.permute(0, 3, 1, 2).double())
+    ns = ops.conv_wgrad_slab_count(B, H, W, Cin, Cout, sc)
+    assert 1 <= ns <= 256
+    slabs = torch.full((ns, 9, Cin, Cout), float("nan"), device=DEV)
+    slabs1 = torch.full((ns, Cin, Cout), float("nan"), device=DEV) if sc else None
+    got_ns = ops.conv_wgrad_slabs(x.to(DEV), dy.to(DEV), None if dy1 is None else dy1.to(DEV), slabs, slabs1,
+                                  B, H, W, Cin, Cout)
+    assert got_ns == ns
+    dW9 = torch.full((Cout, Cin, 3, 3), float("nan"), device=DEV)
+    entries = [(slabs, dW9, ns, 9, Cin, Cout)]
+    if sc:
+        dW1 = torch.full((Cout, Cin, 1, 1), float("nan"), device=DEV)
+        entries.append((slabs1, dW1, ns, 1, Cin, Cout))
+    plan = ops.ReducePlan()
+    plan.run(entries)
+    plan.run(entries)                      # the cached table
+    scale = float(w9.grad.abs().max())
+    assert float((dW9.cpu().double() - w9.grad).abs().max()) < 2e-5 * scale
+    if sc:
+        w1 = torch.zeros(Cout, Cin, 1, 1, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xd, w1).backward(dy1.permute(0, 3, 1, 2).double())
+        assert float((dW1.cpu().double() - w1.grad).abs().max()) < 2e-5 * float(w1.grad.abs().max())

@@ -1,0 +1,82 @@
+// Developer lab for the DMA-fed weight-gradient kernel: event timing of the slab kernel alone.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wgrad2_lab.hip -o tools/wgrad2_lab
+//   tools/wgrad2_lab B H W Cin Cout with_shortcut
+#include "../multimodal-sentiment-analysis_amd/csrc/wgrad.hip"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x)                                                               \
+  do {                                                                      \
+    hipError_t e_ = (x);                                                    \
+    if (e_ != hipSuccess) {                                                 \
+      printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); \
+      return 1;                                                             \
+    }                                                                       \
+  } while (0)
+
+int main(int argc, char** argv) {
+  if (argc < 7) return 1;
+  const int B = atoi(argv[1]), H = atoi(argv[2]), W = atoi(argv[3]), Cin = atoi(argv[4]), Cout = atoi(argv[5]);
+  const int sc = atoi(argv[6]);
+  int dh[9], dw[9];
+  for (int i = 0; i < 9; ++i) { dh[i] = i / 3 - 1; dw[i] = i % 3 - 1; }
+  const size_t nx = (size_t)B * H * W * Cin, ny = (size_t)B * H * W * Cout;
+  std::vector<float> hx(nx), hy(ny);
+  unsigned s = 12345;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+  for (auto& v : hx) v = rnd();
+  for (auto& v : hy) v = rnd();
+  int nslabs = 0;
+  const long fl = mmsa_conv_wgrad_slab_floats(B, H, W, Cin, Cout, sc, &nslabs);
+  if (fl < 0) { printf("bad geometry\n"); return 1; }
+  const Wg2Plan p = wg2_plan(B, H, W, Cin, Cout, sc != 0);
+  float *X, *dY, *dY1, *slabs, *slabs1;
+  CK(hipMalloc(&X, nx * 4)); CK(hipMalloc(&dY, ny * 4)); CK(hipMalloc(&dY1, ny * 4));
+  CK(hipMalloc(&slabs, fl * 4)); CK(hipMalloc(&slabs1, (size_t)nslabs * Cin * Cout * 4));
+  CK(hipMemcpy(X, hx.data(), nx * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dY, hy.data(), ny * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dY1, hy.data(), ny * 4, hipMemcpyHostToDevice));
+  unsigned long long* stamps = nullptr;
+  const size_t nst = 4096 * 4 * 8;
+#ifdef MMSA_LAB_STAMPS
+  CK(hipMalloc(&stamps, nst * 8));
+  CK(hipMemset(stamps, 0, nst * 8));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_wg2_stamps), &stamps, sizeof(stamps)));
+#endif
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  auto run = [&]() { return mmsa_conv_wgrad_slabs(X, dY, sc ? dY1 : nullptr, slabs, slabs1, B, H, W, Cin, Cout, dh, dw, st); };
+  for (int i = 0; i < 50; ++i)
+    if (run() != 0) { printf("launch failed\n"); return 1; }
+  CK(hipStreamSynchronize(st));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int reps = 200;
+  CK(hipEventRecord(e0, st));
+  for (int i = 0; i < reps; ++i) run();
+  CK(hipEventRecord(e1, st));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double flop = 2.0 * B * H * W * Cin * Cout * (sc ? 10 : 9);
+  printf("B=%d H=%d W=%d Cin=%d Cout=%d sc=%d: R=%d strips=%d slabs=%d lds=%zu KB: %.1f us (%.1f TF)\n", B, H, W, Cin,
+         Cout, sc, p.R, p.nstrips, nslabs, p.shmem / 1024, ms * 1e3 / reps, flop / (ms * 1e3 / reps) / 1e6);
+#ifdef MMSA_LAB_STAMPS
+  std::vector<unsigned long long> hs(nst);
+  CK(hipMemcpy(hs.data(), stamps, nst * 8, hipMemcpyDeviceToHost));
+  const int nwg = (Cin / 32) * (Cout / 64) * nslabs;
+  for (int q = 0; q < 4; q += 2) {
+    std::vector<double> v[5];
+    for (int w = 0; w < nwg; ++w)
+      for (int k = 0; k < 5; ++k) v[k].push_back((double)hs[((size_t)w * 4 + q) * 8 + k]);
+    double med[5];
+    for (int k = 0; k < 5; ++k) { std::sort(v[k].begin(), v[k].end()); med[k] = v[k][v[k].size() / 2]; }
+    printf("  wave q=%d: median cycles first strip %.0f, matrix loops %.0f, barrier waits %.0f, slab stores %.0f, total %.0f\n",
+           q / 2, med[0], med[1], med[2], med[3], med[4]);
+  }
+#endif
+  return 0;
+}
