@@ -184,6 +184,11 @@ MMSA_API int mmsa_se_gate(const float* bsum, const float* coeff, const float* W1
 /* out[B,H/2,W/2,C] = maxpool2( relu( BN2(c2) * gate + BN_s(sc) ) ) */
 MMSA_API int mmsa_res_gate_relu_pool(const float* c2, const float* sc, const float* coeff2, const float* coeffs,
                                      const float* gate, float* out, int B, int H, int W, int C, void* stream);
+/* the block tail without the pooling, every part optional: out = [relu]((a*scale2+shift2)*gate + (sc*scale_s+shift_s));
+ * null coefficient table = identity, null gate = 1, null sc = 0: SEBlock.forward alone (multimodal_model.py:38-42:
+ * x * gate) and ResidualBlock.forward alone (:64-70, identity or projection shortcut) */
+MMSA_API int mmsa_gate_affine_add(const float* a, const float* coeff2, const float* gate, const float* sc,
+                                  const float* coeffs, float* out, int B, int P, int C, int relu, void* stream);
 MMSA_API int mmsa_gap_fwd(const float* x, float* out, int B, int P, int C, void* stream);
 MMSA_API int mmsa_gap_bwd(const float* dout, float* dx, int B, int P, int C, void* stream);
 MMSA_API long mmsa_resblock_bwd_scratch_floats(int B, int H, int W, int C);

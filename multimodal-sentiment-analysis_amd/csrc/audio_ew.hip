@@ -418,6 +418,40 @@ __global__ void res_gate_relu_pool_kernel(const float* __restrict__ c2, const fl
   }
 }
 
+// The same arithmetic without the pooling, every part optional: out = [relu]( (a * s2 + h2) * gate + (s * ss + hs) ),
+// a null coefficient table meaning scale 1 / shift 0, a null gate 1, a null second map 0.  Serves the stand-alone
+// SEBlock (x * gate) and ResidualBlock (no pool; identity or projection shortcut) forwards.
+__global__ void gate_affine_add_kernel(const f32x4* __restrict__ a, const float* __restrict__ coeff2,
+                                       const float* __restrict__ gate, const f32x4* __restrict__ sc,
+                                       const float* __restrict__ coeffs, f32x4* __restrict__ out, long n4, int P,
+                                       int C, int relu) {
+  const int c4n = C >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    const long b = i / ((long)c4n * P);
+    const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 s2 = coeff2 ? *reinterpret_cast<const f32x4*>(coeff2 + 2 * C + c) : one;
+    const f32x4 h2 = coeff2 ? *reinterpret_cast<const f32x4*>(coeff2 + 3 * C + c) : zero;
+    const f32x4 gt = gate ? *reinterpret_cast<const f32x4*>(gate + b * C + c) : one;
+    const f32x4 av = a[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = fmaf(av[k], s2[k], h2[k]) * gt[k];
+    if (sc) {
+      const f32x4 ss = coeffs ? *reinterpret_cast<const f32x4*>(coeffs + 2 * C + c) : one;
+      const f32x4 hs = coeffs ? *reinterpret_cast<const f32x4*>(coeffs + 3 * C + c) : zero;
+      const f32x4 sv = sc[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] += fmaf(sv[k], ss[k], hs[k]);
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.f);
+    }
+    out[i] = o;
+  }
+}
+
 __global__ void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int P, int C) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
@@ -878,6 +912,18 @@ MMSA_EXPORT int mmsa_res_gate_relu_pool(const float* c2, const float* sc, const 
   const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
   hipLaunchKernelGGL(res_gate_relu_pool_kernel, dim3(ew_blocks(total)), dim3(256), 0, mmsa_stream(stream), c2, sc,
                      coeff2, coeffs, gate, out, B, H, W, C);
+  return mmsa_launch_status();
+}
+
+// out[B][P][C] = [relu]( (a * scale2 + shift2) * gate[b][c] + (sc * scale_s + shift_s) ); coeff2 / coeffs are
+// [4][C] BatchNorm coefficient tables (rows 2, 3 = scale, shift) or null (identity), gate [B][C] or null (1), sc null (0).
+MMSA_EXPORT int mmsa_gate_affine_add(const float* a, const float* coeff2, const float* gate, const float* sc,
+                                     const float* coeffs, float* out, int B, int P, int C, int relu, void* stream) {
+  MMSA_REQUIRE(a && out && B > 0 && P > 0 && C > 0 && C % 4 == 0 && (sc || !coeffs));
+  const long n4 = (long)B * P * C / 4;
+  hipLaunchKernelGGL(gate_affine_add_kernel, dim3(ew_blocks(n4)), dim3(256), 0, mmsa_stream(stream),
+                     reinterpret_cast<const f32x4*>(a), coeff2, gate, reinterpret_cast<const f32x4*>(sc), coeffs,
+                     reinterpret_cast<f32x4*>(out), n4, P, C, relu);
   return mmsa_launch_status();
 }
 

@@ -20,7 +20,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from . import _lib, audio as audio_engine, head as head_engine, ops, text as text_engine
+from . import _lib, audio as audio_engine, head as head_engine, ops, text as text_engine, torch_ops  # noqa: F401
 from .arena import ParamArena
 from .workspace import Grads, Workspace
 
@@ -49,14 +49,27 @@ def _stack(spec) -> nn.Sequential:
     return nn.Sequential(*[makers[s[0]](*s[1:]) for s in spec])
 
 
-def _no_standalone(name):
-    raise NotImplementedError(
-        f"{name}.forward is fused into its parent's HIP launch sequence and has no stand-alone kernel path; "
-        "call AudioModel / TextModel / MultimodalSentimentModel instead")
+def _standalone_no_grad(module: nn.Module, name: str, *inputs):
+    """The stand-alone forward of a sub-module is a HIP launch sequence without an autograd node: its backward lives in
+    the parent's launch sequence (AudioModel / TextModel / MultimodalSentimentModel).  Rather than hand back a tensor
+    that silently carries no gradient, refuse when one is asked for."""
+    if torch.is_grad_enabled() and (any(p.requires_grad for p in module.parameters())
+                                    or any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs)):
+        raise RuntimeError(f"{name}.forward on its own runs without autograd (wrap the call in torch.no_grad()); "
+                           "gradients flow through AudioModel / TextModel / MultimodalSentimentModel, whose backward "
+                           "is the fused HIP sequence")
+
+
+def _channels_last(x: torch.Tensor, dev) -> torch.Tensor:
+    """[B, C, H, W] (the reference's layout) -> contiguous [B, H, W, C] float32 on the GPU (the kernels' layout)."""
+    if x.dim() != 4:
+        raise ValueError("expected a [B, C, H, W] map")
+    return x.to(device=dev, dtype=torch.float32).permute(0, 2, 3, 1).contiguous()
 
 
 class Attention(nn.Module):
-    """Present for import compatibility (multimodal_model.py:5-24); the reference never instantiates it."""
+    """multimodal_model.py:5-24.  The reference defines it and never instantiates it, so it stays a plain composition:
+    the three projections run on the HIP dense kernel, the two small products and the softmax on torch ops."""
 
     def __init__(self, dim):
         super().__init__()
@@ -64,37 +77,116 @@ class Attention(nn.Module):
         self.scale = dim ** 0.5
 
     def forward(self, x):
-        _no_standalone("Attention")
+        dev = _require_gpu(self, "Attention")
+        _standalone_no_grad(self, "Attention", x)
+        x = x.to(device=dev, dtype=torch.float32)
+        rows = x.reshape(-1, x.shape[-1]).contiguous()
+
+        def proj(lin):
+            y = torch.empty((rows.shape[0], lin.weight.shape[0]), dtype=torch.float32, device=dev)
+            ops.dense_fwd(rows, lin.weight, lin.bias, None, None, y, None, None, ops.EPI_NONE)
+            return y.reshape(*x.shape[:-1], -1)
+        q, k, v = proj(self.query), proj(self.key), proj(self.value)
+        attn = torch.softmax(torch.matmul(q, k.transpose(-2, -1)) / self.scale, dim=-1)
+        return torch.matmul(attn, v)
 
 
 class SEBlock(nn.Module):
-    """Parameters of multimodal_model.py:27-36; evaluated inside the residual-block kernels."""
+    """multimodal_model.py:27-42.  Inside the model the block is evaluated by the residual-block kernels; called on
+    its own it runs global average -> FC -> ReLU -> FC -> sigmoid -> channel scale as three launches."""
 
     def __init__(self, channels, reduction=16):
         super().__init__()
+        self.avg_pool = nn.AdaptiveAvgPool2d(1)
         self.fc = _stack([("lin_nobias", channels, channels // reduction), ("relu",),
                           ("lin_nobias", channels // reduction, channels), ("sigmoid",)])
 
     def forward(self, x):
-        _no_standalone("SEBlock")
+        dev = _require_gpu(self, "SEBlock")
+        _standalone_no_grad(self, "SEBlock", x)
+        W1, W2 = self.fc[0].weight, self.fc[2].weight
+        Ch, C = W1.shape
+        if C > 256 or Ch > 16 or C % 4 or Ch < 1:
+            raise NotImplementedError("the HIP squeeze-excite kernel takes up to 256 channels and 16 hidden units")
+        xl = _channels_last(x, dev)
+        B, H, W, _ = xl.shape
+        if xl.shape[3] != C:
+            raise ValueError(f"SEBlock({C}) got {xl.shape[3]} channels")
+        K = torch.ops.mmsa
+        mean = torch.empty((B, C), dtype=torch.float32, device=dev)
+        K.gap_fwd(xl, mean, B, H * W, C)
+        ident = torch.zeros(4 * C, dtype=torch.float32, device=dev)
+        ident[C:3 * C] = 1.0                        # [mean 0, 1/std 1, scale 1, shift 0]
+        gap, hid, gate = (torch.empty((B, n), dtype=torch.float32, device=dev) for n in (C, Ch, C))
+        K.se_gate(mean, ident, W1, W2, 1, gap, hid, gate, B, C)
+        out = torch.empty_like(xl)
+        K.gate_affine_add(xl, None, gate, None, None, out, B, H * W, C, False)
+        return out.permute(0, 3, 1, 2)
 
 
 class ResidualBlock(nn.Module):
-    """Parameters of multimodal_model.py:46-62 (stride 1 with a projection shortcut is what the model uses)."""
+    """multimodal_model.py:45-70: conv3x3 -> BN -> ReLU -> conv3x3 -> BN -> SE -> (+ shortcut) -> ReLU, the shortcut
+    being the identity when the channel count stays and the stride is 1, else conv1x1 -> BN.  The HIP convolutions are
+    stride 1 (the only stride the model uses): a strided block can be built (same parameters) but not run."""
 
     def __init__(self, in_channels, out_channels, stride=1):
         super().__init__()
-        if stride != 1 or in_channels == out_channels:
-            raise NotImplementedError("the HIP path covers the stride-1 projection-shortcut blocks the model uses")
         self.conv1 = nn.Conv2d(in_channels, out_channels, 3, stride, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(out_channels)
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, 1, 1, bias=False)
         self.bn2 = nn.BatchNorm2d(out_channels)
-        self.shortcut = _stack([("conv1", in_channels, out_channels), ("bn2", out_channels)])
+        self.shortcut = nn.Sequential()
+        if stride != 1 or in_channels != out_channels:
+            self.shortcut = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, stride, bias=False),
+                                          nn.BatchNorm2d(out_channels))
         self.se = SEBlock(out_channels)
+        self.stride = stride
 
     def forward(self, x):
-        _no_standalone("ResidualBlock")
+        dev = _require_gpu(self, "ResidualBlock")
+        _standalone_no_grad(self, "ResidualBlock", x)
+        if self.stride != 1:
+            raise NotImplementedError("the HIP convolution kernels are stride 1 (what the model uses)")
+        Cout, Cin = self.conv1.weight.shape[:2]
+        if Cin % 32 or Cout % 64 or Cout > 256:
+            raise NotImplementedError("HIP residual block: in_channels % 32 == 0, out_channels % 64 == 0 and <= 256")
+        xl = _channels_last(x, dev)
+        B, H, W, _ = xl.shape
+        if xl.shape[3] != Cin:
+            raise ValueError(f"ResidualBlock expects {Cin} channels, got {xl.shape[3]}")
+        K = torch.ops.mmsa
+        training = self.training
+        project = len(self.shortcut) > 0
+        npos = B * H * W
+
+        def conv_bn(conv, bn, X, cin, taps, want_bsum):
+            """conv (+ statistics epilogue) and the BatchNorm coefficient kernel; returns (raw map, coeff, bsum)."""
+            wp = torch.empty(conv.weight.numel(), dtype=torch.float32, device=dev)
+            K.conv_pack_weights(conv.weight, wp, None)
+            Y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
+            rows, tiles = ops.conv_stats_rows(B, H, W, Cout)
+            stats = torch.empty(rows * 2 * Cout, dtype=torch.float32, device=dev) if (training or want_bsum) else None
+            K.conv_fwd(X, wp, Y, stats, B, H, W, cin, Cout, [t[0] for t in taps], [t[1] for t in taps])
+            coeff = torch.empty(4 * Cout, dtype=torch.float32, device=dev)
+            bsum = torch.empty((B, Cout), dtype=torch.float32, device=dev) if want_bsum else None
+            K.bn_finalize(stats, rows, tiles, npos, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                          bn.num_batches_tracked, training, coeff, bsum, Cout)
+            return Y, coeff, bsum
+
+        c1, coeff1, _ = conv_bn(self.conv1, self.bn1, xl, Cin, ops.TAPS3X3, False)
+        h1 = torch.empty_like(c1)
+        K.bn_relu_apply(c1, coeff1, h1, npos, Cout)
+        c2, coeff2, bsum2 = conv_bn(self.conv2, self.bn2, h1, Cout, ops.TAPS3X3, True)
+        W1, W2 = self.se.fc[0].weight, self.se.fc[2].weight
+        gap, hid, gate = (torch.empty((B, n), dtype=torch.float32, device=dev) for n in (Cout, W1.shape[0], Cout))
+        K.se_gate(bsum2, coeff2, W1, W2, H * W, gap, hid, gate, B, Cout)
+        if project:
+            sc, coeffs, _ = conv_bn(self.shortcut[0], self.shortcut[1], xl, Cin, ops.TAPS1X1, False)
+        else:
+            sc, coeffs = xl, None
+        out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
+        K.gate_affine_add(c2, coeff2, gate, sc, coeffs, out, B, H * W, Cout, True)
+        return out.permute(0, 3, 1, 2)
 
 
 def _require_gpu(module: nn.Module, what: str):
@@ -214,7 +306,20 @@ class MultifactorFeatureNormalizer(nn.Module):
         self.text_scale = nn.Parameter(torch.ones(1))
 
     def forward(self, audio_features, text_features):
-        _no_standalone("MultifactorFeatureNormalizer")
+        """multimodal_model.py:216-225: (LayerNorm(audio) * audio_scale, LayerNorm(text) * text_scale)."""
+        dev = _require_gpu(self, "MultifactorFeatureNormalizer")
+        _standalone_no_grad(self, "MultifactorFeatureNormalizer", audio_features, text_features)
+        outs = []
+        for x, norm, scale in ((audio_features, self.audio_norm, self.audio_scale),
+                               (text_features, self.text_norm, self.text_scale)):
+            x = x.to(device=dev, dtype=torch.float32).contiguous()
+            if x.dim() != 2 or x.shape[1] != norm.weight.shape[0]:
+                raise ValueError("features must be [B, dim] with the dims the normaliser was built for")
+            y = torch.empty_like(x)
+            stats = torch.empty(2 * x.shape[0], dtype=torch.float32, device=dev)
+            torch.ops.mmsa.ln_scale_fwd(x, norm.weight, norm.bias, scale, None, y, stats)
+            outs.append(y)
+        return tuple(outs)
 
 
 class ModalityFusion(nn.Module):
@@ -239,7 +344,35 @@ class ModalityFusion(nn.Module):
         return da, dt
 
     def forward(self, audio_features, text_features):
-        _no_standalone("ModalityFusion")
+        """multimodal_model.py:263-285: modality dropout (two host draws, training only), the two projectors
+        (Linear -> LayerNorm -> ReLU -> Dropout), the two-way attention softmax and the weighted sum."""
+        dev = _require_gpu(self, "ModalityFusion")
+        _standalone_no_grad(self, "ModalityFusion", audio_features, text_features)
+        a = audio_features.to(device=dev, dtype=torch.float32).contiguous()
+        t = text_features.to(device=dev, dtype=torch.float32).contiguous()
+        da, dt = self.draw_modality_dropout()
+        if da:
+            a = torch.zeros_like(a)
+        if dt:
+            t = torch.zeros_like(t)
+        B = a.shape[0]
+        Hd = self.output_dim
+        p = self.audio_projector[3].p if self.training else 0.0
+        seed = (torch.initial_seed() * 1000003 + int(torch.randint(0, 2 ** 31, (1,)).item())) & ((1 << 62) - 1) if p > 0 else 0
+        P = torch.empty((B, 2 * Hd), dtype=torch.float32, device=dev)
+        for x, proj, col, sd in ((a, self.audio_projector, 0, seed), (t, self.text_projector, Hd, seed + 1)):
+            lin, norm = proj[0], proj[1]
+            pre = torch.empty((B, Hd), dtype=torch.float32, device=dev)
+            stats = torch.empty(2 * B, dtype=torch.float32, device=dev)
+            torch.ops.mmsa.dense_fwd(x, lin.weight, lin.bias, norm.weight, norm.bias, P[:, col:col + Hd], pre, stats,
+                                     ops.EPI_LN_RELU, p, sd)
+        att = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        torch.ops.mmsa.dense_fwd(P, self.attention[0].weight, self.attention[0].bias, None, None, att, None, None,
+                                 ops.EPI_NONE)
+        wts = torch.empty(2 * B, dtype=torch.float32, device=dev)
+        fused = torch.empty((B, Hd), dtype=torch.float32, device=dev)
+        torch.ops.mmsa.fusion_mix_fwd(P, att, wts, fused)
+        return fused
 
 
 class _ModelFn(torch.autograd.Function):

@@ -492,6 +492,23 @@ def res_gate_relu_pool(c2, sc, coeff2, coeffs, gate, out, B, H, W, C):
               B, H, W, C, _stream())
 
 
+def gate_affine_add(a, coeff2, gate, sc, coeffs, out, B, P, C, relu: bool):
+    """out = [relu]((a * scale2 + shift2) * gate + (sc * scale_s + shift_s)) over [B, P, C] maps; coefficient tables,
+    gate and second map are optional (identity / 1 / 0)."""
+    n = B * P * C
+    if a.numel() != n or out.numel() != n or (sc is not None and sc.numel() != n) or C % 4:
+        raise ValueError("gate_affine_add: bad sizes")
+    for t in (coeff2, coeffs):
+        if t is not None and t.numel() != 4 * C:
+            raise ValueError("gate_affine_add: coefficient tables are [4, C]")
+    if gate is not None and gate.numel() != B * C:
+        raise ValueError("gate_affine_add: gate is [B, C]")
+    if coeffs is not None and sc is None:
+        raise ValueError("gate_affine_add: coeffs without a second map")
+    _lib.call("mmsa_gate_affine_add", _chk(a), _opt(coeff2), _opt(gate), _opt(sc), _opt(coeffs), _chk(out), B, P, C,
+              int(relu), _stream())
+
+
 def gap_fwd(x, out, B, P, C):
     if x.numel() != B * P * C or out.numel() != B * C:
         raise ValueError("gap_fwd: bad sizes")

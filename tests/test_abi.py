@@ -216,3 +216,17 @@ def test_zero_time_shift_raises_and_stops_drawing(monkeypatch):
     seq = iter([0.9, 0.0, 0.7])
     with pytest.raises(RuntimeError):
         AudioTransform(augment=True, device="cpu", waveform_only=True, noise_reduce=False, strict=True)(wave, 22050)
+
+
+def test_torch_custom_ops_are_registered_for_the_gpu_only():
+    """torch.ops.mmsa.* exist after importing the package (the thin custom-op layer over the C ABI); they have no
+    CPU kernel, so a CPU call is refused by the dispatcher instead of silently computing somewhere else."""
+    import torch
+    import mmsa_amd  # noqa: F401
+    from mmsa_amd import torch_ops
+    assert len(set(torch_ops.REGISTERED)) == len(torch_ops.REGISTERED) >= 25
+    for name in torch_ops.REGISTERED:
+        op = getattr(torch.ops.mmsa, name)
+        assert "mmsa::" + name in str(op.default._schema)
+    with pytest.raises(NotImplementedError):
+        torch.ops.mmsa.bn_relu_apply(torch.zeros(8, 4), torch.zeros(16), torch.zeros(8, 4), 8, 4)
