@@ -82,6 +82,91 @@ def allreduce_buckets(flat: torch.Tensor, buckets, group=None, async_op: bool = 
     return handles
 
 
+class _HostStagedGather:
+    """all-gather of a GPU tensor over a host-memory transport (see :class:`_HostStagedSum`)."""
+
+    def __init__(self, out: torch.Tensor, src: torch.Tensor, group):
+        self.out, self.group = out, group
+        self.host = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+        self.host.copy_(src, non_blocking=True)
+        self.copied = torch.cuda.Event()
+        self.copied.record()
+
+    def wait(self):
+        self.copied.synchronize()
+        world = dist.get_world_size(self.group)
+        parts = [torch.empty_like(self.host) for _ in range(world)]
+        dist.all_gather(parts, self.host, group=self.group)
+        self.out.copy_(torch.stack(parts).reshape(self.out.shape), non_blocking=True)
+        return True
+
+
+def allgather_rows(out: torch.Tensor, src: torch.Tensor, group=None, async_op: bool = False):
+    """out[world, ...] <- every rank's src[...] (rank order).  Returns a handle with ``wait()`` when async."""
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        h = _HostStagedGather(out, src, group)
+        if not async_op:
+            h.wait()
+        return h
+    return dist.all_gather_into_tensor(out.view(-1, *src.shape[1:]) if src.dim() > 1 else out.view(-1), src,
+                                       group=group, async_op=async_op)
+
+
+def first_occurrence_mask(ids: torch.Tensor) -> torch.Tensor:
+    """mask[i] = no j < i has ids[j] == ids[i] (static shapes: usable inside a captured launch sequence)."""
+    s, idx = torch.sort(ids, stable=True)
+    first = torch.ones_like(s, dtype=torch.bool)
+    first[1:] = s[1:] != s[:-1]
+    mask = torch.empty_like(first)
+    mask[idx] = first
+    return mask
+
+
+class SparseRowExchange:
+    """Sum over ranks of a row-sparse gradient table (the embedding's data gradient: a rank's batch touches at most
+    B * L of the table's rows) without moving the table: every rank sends (token ids, the table rows at those ids) --
+    ``n * E`` floats instead of ``vocab * E`` -- and adds the gathered rows of all ranks into a zeroed table, rank by
+    rank in rank order.  A row that a rank's batch holds several times is sent once (first occurrence; the repeats
+    travel as zero rows), ids outside the table travel as zero rows, so within one rank's contribution every table
+    element receives at most one non-zero addend: the result is the same on every rank and equals the dense sum
+    ``table_0 + table_1 + ...`` taken in rank order, bit for bit.
+    Traffic per rank: sends n * E * 4 B (4 MiB for 32 x 128 tokens of width 256), receives (world - 1) times that;
+    a ring all-reduce of the 31 MB table moves 2 (world - 1) / world * 31 MB each way."""
+
+    def __init__(self, n: int, width: int, vocab: int, device, group=None):
+        self.n, self.width, self.vocab, self.group = n, width, vocab, group
+        self.world = dist.get_world_size(group)
+        self.rows = torch.zeros((n, width), dtype=torch.float32, device=device)
+        self.ids = torch.zeros((n,), dtype=torch.int64, device=device)
+        self.rows_all = torch.zeros((self.world, n, width), dtype=torch.float32, device=device)
+        self.ids_all = torch.zeros((self.world, n), dtype=torch.int64, device=device)
+
+    def pack(self, table: torch.Tensor, ids: torch.Tensor):
+        """Fills the send buffers from this rank's table (kernel launches on the current stream, static shapes)."""
+        ids = ids.reshape(-1)
+        if ids.numel() != self.n or table.shape != (self.vocab, self.width):
+            raise ValueError("SparseRowExchange.pack: ids / table do not match the exchange's geometry")
+        ok = (ids >= 0) & (ids < self.vocab)
+        safe = torch.where(ok, ids, torch.zeros_like(ids))
+        keep = ok & first_occurrence_mask(safe)
+        self.ids.copy_(safe)
+        torch.index_select(table, 0, safe, out=self.rows)
+        self.rows.mul_(keep.unsqueeze(1).to(self.rows.dtype))
+
+    def start(self):
+        """Issues the two all-gathers (asynchronously); returns their handles."""
+        return [allgather_rows(self.rows_all, self.rows, self.group, async_op=True),
+                allgather_rows(self.ids_all, self.ids, self.group, async_op=True)]
+
+    def finish(self, table: torch.Tensor, handles):
+        """Waits for the gathers and rebuilds the table as the sum over ranks, in rank order."""
+        for h in handles:
+            h.wait()
+        table.zero_()
+        for r in range(self.world):
+            table.index_add_(0, self.ids_all[r], self.rows_all[r])
+
+
 def train_batches(n_items: int, per_rank_batch: int, epoch_seed: int, rank: int, world: int):
     """Index batches for one epoch: a seeded permutation cut into global batches of ``world * per_rank_batch``
     (incomplete tail dropped, as ``drop_last=True``); rank r takes positions ``r::world`` of each global batch."""

@@ -33,6 +33,13 @@ from .workspace import Grads, Workspace
 CAPTURE_MODE = "thread_local"
 
 
+def dist_backend_is_stream_ordered(group) -> bool:
+    """True when waiting for a collective's handle only orders GPU streams (RCCL); a host-memory transport's wait blocks
+    the calling thread instead, so it is better called as late as possible."""
+    import torch.distributed as dist
+    return dist.get_backend(group) == "nccl"
+
+
 class TrainStep:
     def __init__(self, model: MultimodalSentimentModel, lr: float = 1e-3, weight_decay: float = 1e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: Optional[float] = 1.0, frontend=None,
@@ -90,12 +97,22 @@ class TrainStep:
         # MMSA_OVERLAP_ALLREDUCE=1 / 0 forces it on / off)
         want = os.environ.get("MMSA_OVERLAP_ALLREDUCE", "auto")
         self.overlap = self.dist and model.modality == "both" and (want == "1" or (want != "0" and self.world > 1))
+        self._use_sparse = False
+        self._sparse = None
         if self.overlap:
             n_audio = len(list(model.audio_model.parameters()))
             split = self.arena.offsets[n_audio]
-            self._early_buckets = [(split + lo, split + hi) for lo, hi in
-                                   parallel.make_buckets(self.g.numel() - split, bucket)]
             self._late_buckets = parallel.make_buckets(split, bucket)
+            # The embedding table is the first tensor behind the audio branch and 81 % of all gradient bytes, but a
+            # batch touches at most B * L of its 30 522 rows: exchanged as (ids, rows) its traffic is 4 MiB sent and
+            # (world - 1) x 4 MiB received per rank instead of a 31 MB all-reduce.  MMSA_SPARSE_EMB=1 / 0 forces the
+            # row-sparse exchange on / off; by default it is used up to four ranks (at eight, what a rank receives is
+            # only half of a ring all-reduce's traffic, and the exchange ends with world index-add launches).
+            want_sp = os.environ.get("MMSA_SPARSE_EMB", "auto")
+            self._use_sparse = want_sp == "1" or (want_sp != "0" and 1 < self.world <= 4)
+            dense_from = self.arena.offsets[n_audio + 1] if self._use_sparse else split
+            self._early_buckets = [(dense_from + lo, dense_from + hi) for lo, hi in
+                                   parallel.make_buckets(self.g.numel() - dense_from, bucket)]
         from .head import _use_layers
         if use_graph and model.training and model._drop_p() > 0 and (model.modality != "both" or _use_layers()):
             # the fused 'both' head mixes the device-resident step count into its dropout seed; the layer-by-layer
@@ -152,14 +169,41 @@ class TrainStep:
         parallel.allreduce_buckets(self.g, self._buckets, self.pg)
 
     def _allreduce_early(self):
-        """Text-branch and head gradients: issued on the collective's stream, not waited for yet."""
-        return parallel.allreduce_buckets(self.g, self._early_buckets, self.pg, async_op=True)
+        """Text-branch and head gradients: issued on the collective's stream, not waited for yet.  With the row-sparse
+        exchange the embedding table travels as (ids, rows); its gathered rows are summed into the table on a helper
+        stream, beside the audio branch's backward."""
+        handles = parallel.allreduce_buckets(self.g, self._early_buckets, self.pg, async_op=True)
+        if self._use_sparse:
+            emb = self.model.text_model.embedding.weight
+            dtable = self.grads.of(emb)
+            ids = self._cur_ids
+            if self._sparse is None or self._sparse.n != ids.numel():
+                self._sparse = parallel.SparseRowExchange(ids.numel(), emb.shape[1], emb.shape[0], self.arena.device,
+                                                          self.pg)
+            self._sparse.pack(dtable, ids)
+            sp = self._sparse.start()
+            from .audio import FORK_ANY, side_stream
+            self._sparse_pending = None
+            if FORK_ANY and dtable.is_cuda and dist_backend_is_stream_ordered(self.pg):
+                helper = side_stream(self.arena.device, 3)
+                helper.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(helper):
+                    self._sparse.finish(dtable, sp)
+                self._sparse_pending = helper
+            else:
+                self._sparse_pending = (dtable, sp)
+        return handles
 
     def _allreduce_late(self, early):
         """Audio-branch gradients, then make the compute stream wait for both exchanges."""
         late = parallel.allreduce_buckets(self.g, self._late_buckets, self.pg, async_op=True)
         for h in list(early) + list(late):
             h.wait()
+        if self._use_sparse:
+            if isinstance(self._sparse_pending, tuple):
+                self._sparse.finish(*self._sparse_pending)
+            else:
+                torch.cuda.current_stream().wait_stream(self._sparse_pending)
 
     def _update(self, l2: bool):
         """Clip + AdamW over the flat buffers.  self.g holds the DATA gradient only: the regulariser's gradient
@@ -228,6 +272,7 @@ class TrainStep:
                 ins[k] = t.to(device=dev, dtype=want, non_blocking=True).contiguous()
         if not self.use_graph:
             self._copy_inputs(pending)
+            self._cur_ids = ins["input_ids"]
             self._body(ins["audio"], ins["input_ids"], ins["labels"], ins["wave"])
             return self.loss
         # graph mode: inputs are copied into static buffers, the captured launch sequences are replayed.
@@ -247,6 +292,7 @@ class TrainStep:
                 pending.append((s, t))
         self._copy_inputs(pending)
         st = self._static
+        self._cur_ids = st.get("input_ids")
         args = (st.get("audio"), st.get("input_ids"), st.get("labels"), st.get("wave"))
         if self._graph is None:
             if self._warm < 2:                 # eager warm-up: sizes every workspace buffer before capture

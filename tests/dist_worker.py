@@ -71,7 +71,24 @@ def main():
         assert losses[-1] == losses[-1] and abs(losses[-1]) < 1e3 and gn == gn and 0.0 < gn < 1e6, (s, losses[-1], gn)
         print(f"rank {rank} step {s} loss {losses[-1]:.5f}", file=trace, flush=True)
     torch.cuda.synchronize()
-    torch.save({"flat": m._arena.flat.cpu(), "losses": losses}, f"{prefix}.rank{rank}.pt")
+    # the row-sparse exchange alone, on GPU tensors: bit-equal to the dense sum of the same two tables
+    from mmsa_amd import parallel
+    gen = torch.Generator().manual_seed(7 + rank)
+    ids = torch.randint(0, SMALL_VOCAB, (96,), generator=gen)
+    ids[5] = ids[40]                                              # a repeated id
+    table = torch.zeros(SMALL_VOCAB, 16)
+    table[ids] = torch.randn(96, 16, generator=gen)
+    table, ids = table.cuda(), ids.cuda()
+    dense = table.clone()
+    for h in parallel.allreduce_buckets(dense.view(-1), [(0, dense.numel())], None, async_op=True):
+        h.wait()
+    ex = parallel.SparseRowExchange(96, 16, SMALL_VOCAB, torch.device("cuda"))
+    ex.pack(table, ids)
+    ex.finish(table, ex.start())
+    torch.cuda.synchronize()
+    exact = bool(torch.equal(table, dense))
+    torch.save({"flat": m._arena.flat.cpu(), "losses": losses, "sparse": bool(ts._use_sparse),
+                "exchange_exact": exact}, f"{prefix}.rank{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()

@@ -49,7 +49,26 @@ def _worker(rank, world, port, ret):
         P, R = parallel.gather_predictions(probs, preds, n)
         ok = torch.equal(R, torch.arange(n)) and torch.equal(P[:, 0], torch.arange(n, dtype=torch.float32))
         tb = parallel.train_batches(50, 4, 7, rank, world)
-        ret[rank] = (err, ok, [b.tolist() for b in tb])
+        # row-sparse exchange of the embedding table's gradient against the dense all-reduce of the same table
+        table = grads["text_model.embedding.weight"].clone()
+        dense = table.clone()
+        dist.all_reduce(dense)
+        # one extra id outside the table: it travels as a zero row
+        ids = torch.cat([full["input_ids"][idx].reshape(-1), torch.tensor([SMALL_VOCAB + 5])])
+        ex = parallel.SparseRowExchange(ids.numel(), table.shape[1], table.shape[0], torch.device("cpu"))
+        ex.pack(table, ids)
+        ex.finish(table, ex.start())
+        touched = torch.zeros(table.shape[0], dtype=torch.bool)
+        touched[ex.ids_all.reshape(-1)] = True
+        sparse_ok = (torch.equal(table, dense) and not table[~touched].any().item()
+                     and int(touched.sum()) < table.shape[0])
+        parallel.assert_same_on_all_ranks(table, "summed embedding gradient")
+        try:
+            parallel.assert_same_on_all_ranks(torch.full((4,), float(rank)), "rank-dependent tensor")
+            differs = False
+        except RuntimeError:
+            differs = True
+        ret[rank] = (err, (ok, sparse_ok, differs), [b.tolist() for b in tb])
     finally:
         dist.destroy_process_group()
 
@@ -64,7 +83,7 @@ def test_two_rank_allreduce_matches_single_process():
     for r in range(world):
         err, ok, _ = ret[r]
         assert err < 1e-5, err
-        assert ok
+        assert all(ok), ok
     b0, b1 = ret[0][2], ret[1][2]
     assert len(b0) == len(b1) == 50 // 8                      # drop_last over global batches of 8
     seen = [i for a, b in zip(b0, b1) for i in a + b]

@@ -15,18 +15,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.mark.parametrize("use_graph", ["0", "1"])
-def test_two_ranks_sharing_one_gpu(use_graph, tmp_path):
-    """Two data-parallel ranks (gloo over GPU tensors, both on this GPU) against a single-process emulation: per step
-    the gradient is the mean of the two ranks' autograd gradients (each already holds the regulariser's gradient
-    once), clipped at 1.0 and applied by torch.optim.AdamW.  Replicas must stay bit-identical to each other."""
+def _run_two_ranks(use_graph, prefix, port_base, **env):
     import subprocess
     import sys
-    port = str(29800 + (os.getpid() % 150))
-    prefix = str(tmp_path / "dp")
+    port = str(port_base + (os.getpid() % 150))
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), "2", port, prefix, use_graph],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env={**os.environ, **env})
+             for r in range(2)]
     outs = []
     for p in procs:
         try:
@@ -45,6 +41,30 @@ def test_two_ranks_sharing_one_gpu(use_graph, tmp_path):
     r0 = torch.load(prefix + ".rank0.pt", weights_only=True)
     r1 = torch.load(prefix + ".rank1.pt", weights_only=True)
     assert torch.equal(r0["flat"], r1["flat"])
+    return r0, r1
+
+
+def test_row_sparse_and_dense_embedding_exchange_agree(tmp_path):
+    """Six steps with the embedding table's gradient exchanged as (ids, rows) against six steps with the dense
+    all-reduce.  The exchange itself is bit-exact (the workers check that on a seeded table, see dist_worker.py); whole
+    runs are compared within the run-to-run spread of the step's atomically accumulated sums."""
+    sp, _ = _run_two_ranks("0", str(tmp_path / "sp"), 29400, MMSA_SPARSE_EMB="1")
+    de, _ = _run_two_ranks("0", str(tmp_path / "de"), 29600, MMSA_SPARSE_EMB="0")
+    assert sp["sparse"] is True and de["sparse"] is False
+    assert sp["exchange_exact"] and de["exchange_exact"]
+    dl = max(abs(a - b) for a, b in zip(sp["losses"], de["losses"]))
+    d = float(torch.linalg.vector_norm(sp["flat"] - de["flat"]) / torch.linalg.vector_norm(de["flat"]))
+    assert dl < 1e-4 and d < 1e-3, (dl, d)
+
+
+@pytest.mark.parametrize("use_graph", ["0", "1"])
+def test_two_ranks_sharing_one_gpu(use_graph, tmp_path):
+    """Two data-parallel ranks (gloo over GPU tensors, both on this GPU) against a single-process emulation: per step
+    the gradient is the mean of the two ranks' autograd gradients (each already holds the regulariser's gradient
+    once), clipped at 1.0 and applied by torch.optim.AdamW.  Replicas must stay bit-identical to each other.  At two
+    ranks the embedding table's gradient travels row-sparse."""
+    r0, r1 = _run_two_ranks(use_graph, str(tmp_path / "dp"), 29800)
+    assert r0["sparse"] is True
 
     m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
     m.fusion_layer.draw_modality_dropout = lambda: (False, False)
