@@ -693,7 +693,13 @@ WgradPlan plan_wgrad(int B, int H, int W, int Cin, int Cout, int ntaps) {
   p.nstrips = B * p.strips_per_img;
   const int pairs = (Cin / 32) * (Cout / 64);
   const long slab_bytes = (long)ntaps * Cin * Cout * 4 * (ntaps == 1 ? 2 : 1);
-  long max_split = 512 / pairs;                                   // about two workgroups per CU
+  static long wgs = -1;                                           // MMSA_WGRAD_WGS overrides (tuning aid)
+  if (wgs < 0) {
+    const char* e = getenv("MMSA_WGRAD_WGS");
+    wgs = e ? atol(e) : 512;
+    if (wgs < 64) wgs = 512;
+  }
+  long max_split = wgs / pairs;                                   // default: about two workgroups per CU
   static long budget_mb = -1;                                     // MMSA_WGRAD_BUDGET_MB overrides (tuning aid)
   if (budget_mb < 0) {
     const char* e = getenv("MMSA_WGRAD_BUDGET_MB");

@@ -26,6 +26,7 @@
 // [Cout][Cin][kh][kw] layout.
 #include "mmsa_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -37,7 +38,18 @@ struct Wg2Geom {
 
 constexpr int WG2_MAXP = 14;          // LDS-DMA pieces (1 KiB) per wave and strip
 constexpr int WG2_OOB = 0x7ffffff0;   // a byte offset no tensor reaches: the hardware answers with zeros
-constexpr size_t WG2_LDS_BUDGET = 156 * 1024;
+constexpr size_t WG2_LDS_MAX = 156 * 1024;
+// LDS one workgroup may take for its two strip buffers.  MMSA_WGRAD2_LDS_KB overrides (tuning aid): a smaller budget
+// means shorter strips (more halo re-reads), and room on the CU for the small kernels of the data-gradient chain.
+static size_t wg2_lds_budget() {
+  static long kb = -1;
+  if (kb < 0) {
+    const char* e = getenv("MMSA_WGRAD2_LDS_KB");
+    kb = e ? atol(e) : 156;
+    if (kb < 32 || kb > 156) kb = 156;
+  }
+  return (size_t)kb * 1024;
+}
 constexpr size_t WG2_PARK_BYTES = 4 * 5 * 16 * 64 * 4;
 
 struct Wg2Plan {
@@ -58,7 +70,7 @@ Wg2Plan wg2_plan(int B, int H, int W, int Cin, int Cout, bool sc) {
   for (int R = 1; R <= H && R <= 16; ++R) {
     const int xp = ((R + 2) * WP + 7) / 8, yp = (R * W + 3) / 4;
     const int pieces = xp + yp * (sc ? 2 : 1);
-    if (2 * (size_t)pieces * 1024 > WG2_LDS_BUDGET || (pieces + 7) / 8 > WG2_MAXP) break;
+    if (2 * (size_t)pieces * 1024 > wg2_lds_budget() || (pieces + 7) / 8 > WG2_MAXP) break;
     const long cost = (long)((H + R - 1) / R) * (R + 1);
     if (!best || cost <= best_cost) { best = R; best_cost = cost; }
   }
@@ -69,7 +81,13 @@ Wg2Plan wg2_plan(int B, int H, int W, int Cin, int Cout, bool sc) {
   p.xpieces = ((p.R + 2) * WP + 7) / 8;
   p.ypieces = (p.R * W + 3) / 4;
   const int pairs = (Cin / 32) * (Cout / 64);
-  int nsplit = 256 / pairs;
+  static long wgs = -1;                                   // MMSA_WGRAD2_WGS overrides (tuning aid)
+  if (wgs < 0) {
+    const char* e = getenv("MMSA_WGRAD2_WGS");
+    wgs = e ? atol(e) : 256;
+    if (wgs < 32 || wgs > 1024) wgs = 256;
+  }
+  int nsplit = (int)wgs / pairs;
   if (nsplit < 1) nsplit = 1;
   if (nsplit > p.nstrips) nsplit = p.nstrips;
   const int per = (p.nstrips + nsplit - 1) / nsplit;      // strips per workgroup, evenly dealt

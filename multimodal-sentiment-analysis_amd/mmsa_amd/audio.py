@@ -22,16 +22,20 @@ FORK_WGRAD = _os.environ.get("MMSA_FORK_WGRAD", "1") != "0"
 FORK_ANY = _os.environ.get("MMSA_FORK", "1") != "0"     # 0: the whole step on one stream (diagnostics)
 # 1: a block's first 3x3 convolution and its 1x1 shortcut share one launch (and one BatchNorm coefficient launch)
 FWD_PAIR = _os.environ.get("MMSA_FWD_PAIR", "1") != "0"
-# Weight-gradient kernels: "old" (default) = the first generation (two 256-thread workgroups per CU, one reduction
-# launch per layer); "slabs" = the DMA-fed second generation (one 512-thread workgroup per CU, all layers' partial slabs
-# summed by one launch at the end of the backward pass).  Alone, the second generation is faster on every layer
-# (50 vs 71 us with its reduction on the 256 -> 256 layer at batch 32); inside the step it loses: the helper stream's
-# kernels run beside the data-gradient chain, and a kernel that takes all of a CU's LDS and registers displaces that
-# chain's kernels instead of filling its gaps (batch 32, one GPU: 1.44 ms against 1.41 ms per step).
-WGRAD = _os.environ.get("MMSA_WGRAD", "old")
+# Weight-gradient kernels: "slabs" (default) = the DMA-fed second generation (one 512-thread workgroup per CU writes a
+# partial slab; a block's slabs are summed by one launch behind the block's last weight-gradient kernel, or with
+# MMSA_WGRAD_REDUCE=end by one launch for all layers at the end of the backward pass); "old" = the first generation
+# (two 256-thread workgroups per CU, one reduction launch per layer), which also serves maps too wide for a strip in
+# LDS.  Alone, the second generation is faster on every layer (50 vs 71 us with its reduction on the 256 -> 256 layer at
+# batch 32) and writes fewer partial sums; inside the step the two are level (batch 32, one GPU: 1.413 vs 1.405 ms):
+# what the helper stream's kernels hide behind is the data-gradient chain's small element-wise kernels, and the
+# slower generation hides as much more as it is slower (measured without any weight gradient: 1.211 ms; with all of
+# them behind the last data-gradient convolution: 1.585 / 1.511 ms; a single reduction at the end: 1.437 ms).
+WGRAD = _os.environ.get("MMSA_WGRAD", "slabs")
+WGRAD_REDUCE_PER_BLOCK = _os.environ.get("MMSA_WGRAD_REDUCE", "block") == "block"
 # 1: every weight-gradient launch waits until the last data-gradient convolution has been launched, then the whole
 # chain runs beside the stem's backward.  0 (default): each launch from its own fork point, as early as its inputs
-# exist (measured: 1.41 vs 1.59 ms per step with the first-generation kernels, 1.44 vs 1.51 with the second).
+# exist.
 WGRAD_DEFER = _os.environ.get("MMSA_WGRAD_DEFER", "0") != "0"
 
 
@@ -206,7 +210,9 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
         sls = ws.buf(name + ".sc.slabs", (n1, Cin, Cout))
         if reduce_list is None:
             raise ValueError("block_backward: the slab path needs a reduce list")
-        reduce_list += [(sl2, gw2, n2, 9, Cout, Cout), (sl1, gw1, n1, 9, Cin, Cout), (sls, gws, n1, 1, Cin, Cout)]
+        entries = [(sl2, gw2, n2, 9, Cout, Cout), (sl1, gw1, n1, 9, Cin, Cout), (sls, gws, n1, 1, Cin, Cout)]
+        if not WGRAD_REDUCE_PER_BLOCK:
+            reduce_list += entries
 
         def wgrad_conv2():                        # needs d_c2 (and the scratch of the elementwise backward)
             ops.resblock_bwd_se_wgrad(scratch, s.hid, s.gap, grads.of(W1), grads.of(W2), B, H, W, Cout)
@@ -214,6 +220,11 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
 
         def wgrad_conv1_shortcut():               # needs d_c1 and d_sc; both read the block input
             ops.conv_wgrad_slabs(s.a_in, d_c1, d_sc, sl1, sls, B, H, W, Cin, Cout)
+            if WGRAD_REDUCE_PER_BLOCK:
+                plan = ws.objs.get(name + ".reduceplan") or ops.ReducePlan()
+                if ws.persistent:
+                    ws.objs[name + ".reduceplan"] = plan
+                plan.run(entries)
     else:
         wsz = max(ops.conv_wgrad_workspace(B, H, W, Cout, Cout, 9), ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 9))
         wg = ws.buf(name + ".wgrad_ws", wsz)

@@ -377,7 +377,7 @@ def conv_wgrad_slabs(X, dY, dY_sc, slabs, slabs_sc, B, H, W, Cin, Cout, taps=Non
     ns = conv_wgrad_slab_count(B, H, W, Cin, Cout, dY_sc is not None)
     if slabs.numel() < ns * 9 * Cin * Cout or (dY_sc is not None and (slabs_sc is None or slabs_sc.numel() < ns * Cin * Cout)):
         raise ValueError("conv_wgrad_slabs: slab buffer too small")
-    kind = "conv_wgrad2_kernel<%s>" % ("true" if dY_sc is not None else "false")
+    kind = "conv_wgrad2_kernel<%s,%d>" % ("true" if dY_sc is not None else "false", W if W in (16, 32, 65) else 0)
     ev = _prof_begin(kind, 2.0 * n * Cin * Cout * (10 if dY_sc is not None else 9))
     _lib.call("mmsa_conv_wgrad_slabs", _chk(X), _chk(dY), _opt(dY_sc), _chk(slabs), _opt(slabs_sc), B, H, W, Cin, Cout,
               _iarr([t[0] for t in taps]), _iarr([t[1] for t in taps]), _stream())
