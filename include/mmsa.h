@@ -314,11 +314,24 @@ MMSA_API int mmsa_l2_grad_add(float* g, const float* p, const float* tnorm, floa
 MMSA_API int mmsa_grad_norm(const float* g, const float* p, const float* tnorm, float lambda,
                             const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,
                             const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* state, void* stream);
+/* The same norm in two parts, for a backward pass whose gradients become final at different times (the reference
+ * computes it in one go, multimodal_train.py:194): mmsa_grad_chunk_sums takes the sums of squares of chunks
+ * [c_first, c_first + c_count) as soon as those are final; mmsa_grad_norm_finish adds chunks [0, c_rest), writes the
+ * total norm to state[4] and advances the step scalars in the same launch (then call mmsa_adamw_step with
+ * scalars_ready = 1). */
+MMSA_API int mmsa_grad_chunk_sums(const float* g, const float* p, const float* tnorm, float lambda,
+                                  const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,
+                                  int c_first, int c_count, double* chunk_ss, void* stream);
+MMSA_API int mmsa_grad_norm_finish(const float* g, const float* p, const float* tnorm, float lambda,
+                                   const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,
+                                   int c_rest, const int* tensor_first_chunk, int ntensors, double* chunk_ss,
+                                   float* state, float beta1, float beta2, float max_norm, int do_clip, void* stream);
 /* state (8 floats): 0 step, 1 1-beta1^t, 2 sqrt(1-beta2^t), 3 clip coefficient, 4 total grad norm, 5 sum of norms */
 MMSA_API int mmsa_adamw_step(float* p, const float* g, float* m, float* v, const long long* chunk_off,
                              const int* chunk_len, const int* chunk_tensor, int nchunks, const float* tnorm,
                              float lambda, float* state, float lr, float beta1, float beta2, float eps,
-                             float weight_decay, float max_norm, int do_clip, double* chunk_ss_new, void* stream);
+                             float weight_decay, float max_norm, int do_clip, double* chunk_ss_new, int scalars_ready,
+                             void* stream);
 MMSA_API int mmsa_scale_by_state(float* g, long n, const float* state, int idx, void* stream);
 MMSA_API int mmsa_scalar_axpy(float* dst, const float* a, const float* b, float alpha, void* stream);
 /* Up to four device-to-device copies in one launch: a step's inputs into the fixed buffers that a replayed launch

@@ -24,9 +24,9 @@ __global__ __launch_bounds__(256) void chunk_sumsq_kernel(const float* __restric
                                                           const long long* __restrict__ chunk_off,
                                                           const int* __restrict__ chunk_len,
                                                           const int* __restrict__ chunk_tensor,
-                                                          double* __restrict__ chunk_ss) {
+                                                          double* __restrict__ chunk_ss, int c_first) {
   __shared__ double red[16];
-  const int c = blockIdx.x;
+  const int c = c_first + blockIdx.x;
   const float* pa = a + chunk_off[c];
   const int n = chunk_len[c];
   float coef = 0.f;
@@ -61,11 +61,29 @@ __global__ __launch_bounds__(256) void chunk_sumsq_kernel(const float* __restric
   if (threadIdx.x == 0) chunk_ss[c] = s;
 }
 
+// One thread: advances the step count and derives the bias corrections and the clip coefficient from the total norm.
+__device__ __forceinline__ void step_scalars(float* __restrict__ state, float beta1, float beta2, float max_norm,
+                                             int do_clip, float gnorm) {
+  const float t = state[ST_STEP] + 1.f;
+  state[ST_STEP] = t;
+  state[ST_BC1] = 1.f - powf(beta1, t);
+  state[ST_BC2S] = sqrtf(1.f - powf(beta2, t));
+  float coef = 1.f;
+  if (do_clip) coef = fminf(max_norm / (gnorm + 1e-6f), 1.f);
+  state[ST_CLIP] = coef;
+}
+
+struct StepScalars {   // state == nullptr: tensor_norms_kernel leaves the step scalars alone
+  float* state;
+  float beta1, beta2, max_norm;
+  int do_clip;
+};
+
 // per-tensor norms from chunk sums; out_sum = sum_t norm_t (fp32, registration order), out_l2 = sqrt(sum_t norm_t^2)
 __global__ __launch_bounds__(1024) void tensor_norms_kernel(const double* __restrict__ chunk_ss,
                                                             const int* __restrict__ tensor_first_chunk, int ntensors,
                                                             float* __restrict__ tnorm, float* __restrict__ out_sum,
-                                                            float* __restrict__ out_l2) {
+                                                            float* __restrict__ out_l2, const StepScalars sc) {
   // one wave per tensor (16 waves take tensors round-robin), lanes stride over the tensor's chunk sums
   __shared__ float nrm[1024];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -88,7 +106,9 @@ __global__ __launch_bounds__(1024) void tensor_norms_kernel(const double* __rest
       sq += (double)nrm[t] * (double)nrm[t];
     }
     if (out_sum) out_sum[0] = acc;
-    if (out_l2) out_l2[0] = (float)sqrt(sq);
+    const float l2 = (float)sqrt(sq);
+    if (out_l2) out_l2[0] = l2;
+    if (sc.state) step_scalars(sc.state, sc.beta1, sc.beta2, sc.max_norm, sc.do_clip, l2);
   }
 }
 
@@ -106,13 +126,7 @@ __global__ void l2_grad_add_kernel(float* __restrict__ g, const float* __restric
 }
 
 __global__ void step_scalars_kernel(float* __restrict__ state, float beta1, float beta2, float max_norm, int do_clip) {
-  const float t = state[ST_STEP] + 1.f;
-  state[ST_STEP] = t;
-  state[ST_BC1] = 1.f - powf(beta1, t);
-  state[ST_BC2S] = sqrtf(1.f - powf(beta2, t));
-  float coef = 1.f;
-  if (do_clip) coef = fminf(max_norm / (state[ST_GNORM] + 1e-6f), 1.f);
-  state[ST_CLIP] = coef;
+  step_scalars(state, beta1, beta2, max_norm, do_clip, state[ST_GNORM]);
 }
 
 __global__ void scale_inplace_by_state_kernel(float* __restrict__ g, long n, const float* __restrict__ state, int idx) {
@@ -200,9 +214,9 @@ MMSA_EXPORT int mmsa_param_norms(const float* p, const long long* chunk_off, con
   hipStream_t s = mmsa_stream(stream);
   if (!chunk_sums_ready)   // otherwise chunk_ss already holds the sums (written by the previous mmsa_adamw_step)
     hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, p, (const float*)nullptr,
-                       (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss);
+                       (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss, 0);
   hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors, tnorm,
-                     sum_out, (float*)nullptr);
+                     sum_out, (float*)nullptr, StepScalars{});
   return mmsa_launch_status();
 }
 
@@ -226,22 +240,60 @@ MMSA_EXPORT int mmsa_grad_norm(const float* g, const float* p, const float* tnor
   MMSA_REQUIRE((p == nullptr) == (tnorm == nullptr));
   hipStream_t s = mmsa_stream(stream);
   hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, g, p, tnorm, lambda, chunk_off, chunk_len,
-                     chunk_tensor, chunk_ss);
+                     chunk_tensor, chunk_ss, 0);
   hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors,
-                     (float*)nullptr, (float*)nullptr, state + ST_GNORM);
+                     (float*)nullptr, (float*)nullptr, state + ST_GNORM, StepScalars{});
+  return mmsa_launch_status();
+}
+
+// The same norm in two parts, for a backward pass whose gradients become final at different times.
+// mmsa_grad_chunk_sums: the sums of squares of chunks [c_first, c_first + c_count) -> chunk_ss (one launch; call it
+// as soon as those chunks' gradients are final, on any stream).
+MMSA_EXPORT int mmsa_grad_chunk_sums(const float* g, const float* p, const float* tnorm, float lambda,
+                                     const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
+                                     int nchunks, int c_first, int c_count, double* chunk_ss, void* stream) {
+  MMSA_REQUIRE(g && chunk_off && chunk_len && chunk_tensor && chunk_ss);
+  MMSA_REQUIRE((p == nullptr) == (tnorm == nullptr));
+  MMSA_REQUIRE(c_first >= 0 && c_count > 0 && c_first + c_count <= nchunks);
+  hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(c_count), dim3(256), 0, mmsa_stream(stream), g, p, tnorm, lambda, chunk_off,
+                     chunk_len, chunk_tensor, chunk_ss, c_first);
+  return mmsa_launch_status();
+}
+
+// mmsa_grad_norm_finish: the sums of the remaining chunks [0, c_rest) (c_rest may be 0), then the total norm
+// -> state[4] and, in the same launch, the step scalars mmsa_adamw_step would derive (step count + 1, bias corrections,
+// clip coefficient): follow it with mmsa_adamw_step(..., scalars_ready = 1).
+MMSA_EXPORT int mmsa_grad_norm_finish(const float* g, const float* p, const float* tnorm, float lambda,
+                                      const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
+                                      int nchunks, int c_rest, const int* tensor_first_chunk, int ntensors,
+                                      double* chunk_ss, float* state, float beta1, float beta2, float max_norm,
+                                      int do_clip, void* stream) {
+  MMSA_REQUIRE(g && chunk_off && chunk_len && chunk_tensor && tensor_first_chunk && chunk_ss && state);
+  MMSA_REQUIRE(nchunks > 0 && ntensors > 0 && ntensors <= 1024 && c_rest >= 0 && c_rest <= nchunks);
+  MMSA_REQUIRE((p == nullptr) == (tnorm == nullptr));
+  hipStream_t s = mmsa_stream(stream);
+  if (c_rest > 0)
+    hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(c_rest), dim3(256), 0, s, g, p, tnorm, lambda, chunk_off, chunk_len,
+                       chunk_tensor, chunk_ss, 0);
+  hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors,
+                     (float*)nullptr, (float*)nullptr, state + ST_GNORM,
+                     StepScalars{state, beta1, beta2, max_norm, do_clip});
   return mmsa_launch_status();
 }
 
 // One AdamW step over the chunks of the flat buffers.  state[0] (step count) advances by one; the clip coefficient
 // is derived from state[4] (call mmsa_grad_norm first) when do_clip != 0.  With tnorm given, lambda * p / ||p|| is
-// added to every gradient element on the fly (pass null / 0 for plain AdamW).
+// added to every gradient element on the fly (pass null / 0 for plain AdamW).  scalars_ready != 0: the step count and
+// the coefficients in state[] were already advanced for this step by mmsa_grad_norm_finish.
 MMSA_EXPORT int mmsa_adamw_step(float* p, const float* g, float* m, float* v, const long long* chunk_off,
                                 const int* chunk_len, const int* chunk_tensor, int nchunks, const float* tnorm,
                                 float lambda, float* state, float lr, float beta1, float beta2, float eps,
-                                float weight_decay, float max_norm, int do_clip, double* chunk_ss_new, void* stream) {
+                                float weight_decay, float max_norm, int do_clip, double* chunk_ss_new,
+                                int scalars_ready, void* stream) {
   MMSA_REQUIRE(p && g && m && v && state && chunk_off && chunk_len && chunk_tensor && nchunks > 0);
   hipStream_t s = mmsa_stream(stream);
-  hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, s, state, beta1, beta2, max_norm, do_clip);
+  if (!scalars_ready)
+    hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, s, state, beta1, beta2, max_norm, do_clip);
   hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, s, p, g, m, v, chunk_off, chunk_len, chunk_tensor, tnorm,
                      lambda, state, lr, beta1, beta2, eps, weight_decay, chunk_ss_new);
   return mmsa_launch_status();

@@ -547,20 +547,25 @@ class MultimodalSentimentModel(nn.Module):
             run.touched = {id(p) for p in self.parameters()}
         return run
 
-    def _backward(self, run, dlogits, grads: Grads, ws: Optional[Workspace] = None, phase: str = "all"):
+    def _backward(self, run, dlogits, grads: Grads, ws: Optional[Workspace] = None, phase: str = "all",
+                  after_early=None):
         """``phase`` splits the 'both' backward for data-parallel runs: "early" = head + text branch (their gradients,
-        87 % of the bytes, can be exchanged while the rest runs), "late" = audio branch."""
+        87 % of the bytes, can be exchanged while the rest runs), "late" = audio branch.  ``after_early`` (phase "all",
+        modality 'both'): a pair of callables, the first enqueued behind the text branch's backward on its helper
+        stream, the second behind the head's parameter gradients on theirs (both beside the audio branch's backward)."""
         ws = ws or Workspace(dlogits.device, persistent=False)
         if phase != "all" and self.modality != "both":
             raise ValueError("the split backward exists for modality 'both' only")
         dev = dlogits.device if dlogits is not None else self._arena.device
 
-        def side_work():
+        def side_work(then=None):
             """Everything that only the optimiser or the caller reads: the head's parameter gradients, then the loss
             values, on helper stream 2."""
             for fn in getattr(run.head, "side_work", []):
                 fn()
-            deferred = getattr(run.head, "deferred", [])
+            deferred = list(getattr(run.head, "deferred", []))
+            if then is not None:
+                deferred.append(then)
             if deferred:
                 with audio_engine.fork(ws, dev, 2):
                     for fn in deferred:
@@ -582,7 +587,9 @@ class MultimodalSentimentModel(nn.Module):
             # then start at once on helper queues), the audio chain after them
             with audio_engine.fork(ws, dev, 1) as f:
                 text_engine.text_backward(self.text_model, run.text, d_t, grads)
-            side_work()
+                if after_early is not None:
+                    after_early[0]()
+            side_work(after_early[1] if after_early is not None else None)
             audio_engine.audio_backward(self.audio_model, run.audio, d_a, self.audio_model.training, grads, ws)
             f.join()
         elif self.modality == "audio":

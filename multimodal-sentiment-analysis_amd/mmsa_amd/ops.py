@@ -825,15 +825,33 @@ def grad_norm(gflat, table, state, pflat=None, tnorm=None, lam=0.0):
               _chk(state), _stream())
 
 
+def grad_chunk_sums(gflat, table, c_first, c_count, pflat=None, tnorm=None, lam=0.0):
+    """First part of :func:`grad_norm` taken early: the sums of squares of chunks [c_first, c_first + c_count)."""
+    _lib.call("mmsa_grad_chunk_sums", _chk(gflat), _opt(pflat), _opt(tnorm), float(lam), _chk(table.chunk_off, torch.int64),
+              _chk(table.chunk_len, torch.int32), _chk(table.chunk_tensor, torch.int32), table.nchunks, int(c_first),
+              int(c_count), _chk(table.chunk_ss, torch.float64), _stream())
+
+
+def grad_norm_finish(gflat, table, state, c_rest, beta1, beta2, max_norm, do_clip, pflat=None, tnorm=None, lam=0.0):
+    """Second part: the sums of chunks [0, c_rest), the total norm -> state[4], and the step's scalars (step count,
+    bias corrections, clip coefficient) in the same launch; :func:`adamw_step` then takes ``scalars_ready=True``."""
+    _lib.call("mmsa_grad_norm_finish", _chk(gflat), _opt(pflat), _opt(tnorm), float(lam),
+              _chk(table.chunk_off, torch.int64), _chk(table.chunk_len, torch.int32),
+              _chk(table.chunk_tensor, torch.int32), table.nchunks, int(c_rest),
+              _chk(table.tensor_first_chunk, torch.int32), table.ntensors, _chk(table.chunk_ss, torch.float64),
+              _chk(state), float(beta1), float(beta2), float(max_norm), int(do_clip), _stream())
+
+
 def adamw_step(p, g, m, v, table, state, lr, beta1, beta2, eps, wd, max_norm, do_clip, tnorm=None, lam=0.0,
-               emit_param_sums=False):
+               emit_param_sums=False, scalars_ready=False):
     n = p.numel()
     if g.numel() != n or m.numel() != n or v.numel() != n or state.numel() < 8:
         raise ValueError("adamw_step: size mismatch")
     _lib.call("mmsa_adamw_step", _chk(p), _chk(g), _chk(m), _chk(v), _chk(table.chunk_off, torch.int64),
               _chk(table.chunk_len, torch.int32), _chk(table.chunk_tensor, torch.int32), table.nchunks, _opt(tnorm),
               float(lam), _chk(state), float(lr), float(beta1), float(beta2), float(eps), float(wd), float(max_norm),
-              int(do_clip), _chk(table.chunk_ss_p, torch.float64) if emit_param_sums else None, _stream())
+              int(do_clip), _chk(table.chunk_ss_p, torch.float64) if emit_param_sums else None, int(scalars_ready),
+              _stream())
 
 
 def scale_by_state(g, state, idx):

@@ -93,7 +93,7 @@ def test_bad_arguments_are_rejected_before_any_launch():
     assert lib.mmsa_conv_fwd(None, None, None, None, 1, 1, 1, 32, 64, 9, None, None, 0, None) == -1
     assert lib.mmsa_embedding_gather(None, None, None, 4, 256, 1000, None, None) == -1
     assert lib.mmsa_adamw_step(None, None, None, None, None, None, None, 4, None, 0.0, None, 1e-3, 0.9, 0.999, 1e-8,
-                               0.0, 1.0, 1, None, None) == -1
+                               0.0, 1.0, 1, None, 0, None) == -1
     with pytest.raises(_lib.MmsaError):
         _lib.call("mmsa_softmax_ce", None, None, None, None, None, 4, 3, None)
 
