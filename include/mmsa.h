@@ -155,7 +155,9 @@ MMSA_API int mmsa_conv_wgrad_reduce_multi(const void* descs_device, int n, int t
 
 /* ---- audio branch, bandwidth-bound parts: multimodal_model.py:78-83 (stem), :27-42 (SEBlock), :64-70
  *      (ResidualBlock tail), :87-96,118-127 (pools, global average). ----------------------------------------- */
-/* stem Conv2d(1,32,3,pad 1,bias): per-row partial sums of the conv output, partial [2][32][B*H] */
+/* stem Conv2d(1,32,3,pad 1,bias): partial sums / sums of squares of the conv output per group of image rows,
+ * partial [2][32][rows] with rows = mmsa_stem_stats_rows(B, H) (the row count mmsa_bn_finalize then takes) */
+MMSA_API int mmsa_stem_stats_rows(int B, int H);
 MMSA_API int mmsa_stem_stats(const float* x, const float* w, const float* bias, float* partial, int B, int H, int W,
                              void* stream);
 /* stem conv + BN (coeff [4][32]) + ReLU + MaxPool2d(2) -> out [B][H/2][W/2][32] */
@@ -314,18 +316,12 @@ MMSA_API int mmsa_l2_grad_add(float* g, const float* p, const float* tnorm, floa
 MMSA_API int mmsa_grad_norm(const float* g, const float* p, const float* tnorm, float lambda,
                             const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,
                             const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* state, void* stream);
-/* The same norm in two parts, for a backward pass whose gradients become final at different times (the reference
- * computes it in one go, multimodal_train.py:194): mmsa_grad_chunk_sums takes the sums of squares of chunks
- * [c_first, c_first + c_count) as soon as those are final; mmsa_grad_norm_finish adds chunks [0, c_rest), writes the
- * total norm to state[4] and advances the step scalars in the same launch (then call mmsa_adamw_step with
- * scalars_ready = 1). */
-MMSA_API int mmsa_grad_chunk_sums(const float* g, const float* p, const float* tnorm, float lambda,
-                                  const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,
-                                  int c_first, int c_count, double* chunk_ss, void* stream);
+/* mmsa_grad_norm that also advances the step scalars in its second launch (step count + 1, bias corrections, clip
+ * coefficient): follow it with mmsa_adamw_step(..., scalars_ready = 1).  multimodal_train.py:194-195. */
 MMSA_API int mmsa_grad_norm_finish(const float* g, const float* p, const float* tnorm, float lambda,
                                    const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,
-                                   int c_rest, const int* tensor_first_chunk, int ntensors, double* chunk_ss,
-                                   float* state, float beta1, float beta2, float max_norm, int do_clip, void* stream);
+                                   const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* state,
+                                   float beta1, float beta2, float max_norm, int do_clip, void* stream);
 /* state (8 floats): 0 step, 1 1-beta1^t, 2 sqrt(1-beta2^t), 3 clip coefficient, 4 total grad norm, 5 sum of norms */
 MMSA_API int mmsa_adamw_step(float* p, const float* g, float* m, float* v, const long long* chunk_off,
                              const int* chunk_len, const int* chunk_tensor, int nchunks, const float* tnorm,
@@ -337,6 +333,9 @@ MMSA_API int mmsa_scalar_axpy(float* dst, const float* a, const float* b, float 
 /* Up to four device-to-device copies in one launch: a step's inputs into the fixed buffers that a replayed launch
  * sequence reads (the reference moves each batch tensor with its own .to(DEVICE), multimodal_train.py:158-173).
  * srcs / dsts / bytes are host arrays of n <= 4 entries; sizes are multiples of 4 bytes. */
+/* Diagnostic (no counterpart in the reference): buf[slot] <- the GPU's 100 MHz real-time counter when `stream` reaches
+ * this point; see tools/step_stamps.py. */
+MMSA_API int mmsa_stamp(unsigned long long* buf, int slot, void* stream);
 MMSA_API int mmsa_copy_multi(const void* const* srcs, void* const* dsts, const long* bytes, int n, void* stream);
 
 #ifdef __cplusplus

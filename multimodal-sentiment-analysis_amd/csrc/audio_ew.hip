@@ -37,16 +37,30 @@ __device__ __forceinline__ void stem_stage_rows(float* rows, int ldw, const floa
   }
 }
 
-// one block per input row (b,h): per-channel sum / sum of squares of the conv output
+constexpr int STEM_ROWS = 8;   // image rows per workgroup of the statistics kernel (one per group of 32 lanes)
+
+// 3x3 convolution value from a register window (same order of operations as stem_conv)
+__device__ __forceinline__ float stem_conv_win(float a0, float a1, float a2, float b0, float b1, float b2, float c0,
+                                               float c1, float c2, const float* k, float bias) {
+  float a = bias;
+  a = fmaf(k[0], a0, a); a = fmaf(k[1], a1, a); a = fmaf(k[2], a2, a);
+  a = fmaf(k[3], b0, a); a = fmaf(k[4], b1, a); a = fmaf(k[5], b2, a);
+  a = fmaf(k[6], c0, a); a = fmaf(k[7], c1, a); a = fmaf(k[8], c2, a);
+  return a;
+}
+
+// one block per group of STEM_ROWS input rows of one image: per-channel sum / sum of squares of the conv output.
+// Lane group pl (32 lanes = the 32 channels) walks along row h0 + pl with a 3x3 window in registers: three LDS reads
+// (broadcast over the group) per nine multiply-adds.
 __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
                                                          const float* __restrict__ bias, float* __restrict__ partial,
-                                                         int H, int W) {
+                                                         int H, int W, int groups_per_img) {
   extern __shared__ float sm[];
   const int ldw = W + 2;
-  float* rows = sm;                 // [3][ldw]
-  float* red = sm + 3 * ldw;        // [8][2][32]
-  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
-  stem_stage_rows<3>(rows, ldw, x + (long)b * H * W, h - 1, H, W);
+  float* rows = sm;                               // [STEM_ROWS + 2][ldw]
+  float* red = sm + (STEM_ROWS + 2) * ldw;        // [8][2][32]
+  const int b = blockIdx.x / groups_per_img, h0 = (blockIdx.x - b * groups_per_img) * STEM_ROWS;
+  stem_stage_rows<STEM_ROWS + 2>(rows, ldw, x + (long)b * H * W, h0 - 1, H, W);
   const int c = threadIdx.x & 31, pl = threadIdx.x >> 5;
   float k[9];
 #pragma unroll
@@ -54,10 +68,18 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict
   const float bs = bias[c];
   __syncthreads();
   float s = 0.f, q = 0.f;
-  for (int w = pl; w < W; w += 8) {
-    const float v = stem_conv(rows, rows + ldw, rows + 2 * ldw, w, k, bs);
-    s += v;
-    q = fmaf(v, v, q);
+  if (h0 + pl < H) {
+    const float* r0 = rows + pl * ldw;
+    const float* r1 = r0 + ldw;
+    const float* r2 = r1 + ldw;
+    float a0 = r0[0], a1 = r0[1], b0 = r1[0], b1 = r1[1], c0 = r2[0], c1 = r2[1];
+    for (int w = 0; w < W; ++w) {
+      const float a2 = r0[w + 2], b2 = r1[w + 2], c2 = r2[w + 2];
+      const float v = stem_conv_win(a0, a1, a2, b0, b1, b2, c0, c1, c2, k, bs);
+      s += v;
+      q = fmaf(v, v, q);
+      a0 = a1; a1 = a2; b0 = b1; b1 = b2; c0 = c1; c1 = c2;
+    }
   }
   red[(pl * 2 + 0) * 32 + c] = s;
   red[(pl * 2 + 1) * 32 + c] = q;
@@ -71,7 +93,9 @@ __global__ __launch_bounds__(256) void stem_stats_kernel(const float* __restrict
   }
 }
 
-// one block per pooled row (b,h2): recompute conv, BN, ReLU, 2x2 max -> out[b][h2][w2][32]
+// one block per pooled row (b,h2): recompute conv, BN, ReLU, 2x2 max -> out[b][h2][w2][32].  Lane group pl takes a
+// run of consecutive pooled columns and slides a 4x4 window along the four staged rows: eight LDS reads per pooled
+// value (four convolution values).
 __global__ __launch_bounds__(256) void stem_apply_pool_kernel(const float* __restrict__ x, const float* __restrict__ wgt,
                                                               const float* __restrict__ bias,
                                                               const float* __restrict__ coeff, float* __restrict__ out,
@@ -86,16 +110,37 @@ __global__ __launch_bounds__(256) void stem_apply_pool_kernel(const float* __res
   for (int i = 0; i < 9; ++i) k[i] = wgt[c * 9 + i];
   const float bs = bias[c], sc = coeff[2 * STEM_C + c], sh = coeff[3 * STEM_C + c];
   __syncthreads();
-  for (int w2 = pl; w2 < W2; w2 += 8) {
+  const int per = (W2 + 7) / 8;
+  const int w_first = pl * per, w_last = min(W2, w_first + per);
+  if (w_first >= w_last) return;
+  float win[4][4];   // rows 0..3 of the staged block, columns 2*w2 .. 2*w2 + 3 (staged column index)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    win[r][0] = sm[r * ldw + 2 * w_first];
+    win[r][1] = sm[r * ldw + 2 * w_first + 1];
+  }
+  float* o = out + (((long)b * H2 + h2) * W2) * STEM_C + c;
+  for (int w2 = w_first; w2 < w_last; ++w2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      win[r][2] = sm[r * ldw + 2 * w2 + 2];
+      win[r][3] = sm[r * ldw + 2 * w2 + 3];
+    }
     float m = 0.f;  // ReLU folded into the max
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const float v = stem_conv(sm + i * ldw, sm + (i + 1) * ldw, sm + (i + 2) * ldw, 2 * w2 + j, k, bs);
+        const float v = stem_conv_win(win[i][j], win[i][j + 1], win[i][j + 2], win[i + 1][j], win[i + 1][j + 1],
+                                      win[i + 1][j + 2], win[i + 2][j], win[i + 2][j + 1], win[i + 2][j + 2], k, bs);
         m = fmaxf(m, fmaf(v, sc, sh));
       }
-    out[(((long)b * H2 + h2) * W2 + w2) * STEM_C + c] = m;
+    o[(long)w2 * STEM_C] = m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      win[r][0] = win[r][2];
+      win[r][1] = win[r][3];
+    }
   }
 }
 
@@ -818,11 +863,19 @@ inline int ew_blocks(long n, int per_block = 256) {
 }  // namespace
 
 // ================================================================================================ C ABI
+// Rows of the statistics table mmsa_stem_stats writes (partial[2][32][rows]; pass the same count to mmsa_bn_finalize).
+MMSA_EXPORT int mmsa_stem_stats_rows(int B, int H) {
+  if (B <= 0 || H <= 0) return MMSA_ERR_ARG;
+  return B * ((H + STEM_ROWS - 1) / STEM_ROWS);
+}
+
 MMSA_EXPORT int mmsa_stem_stats(const float* x, const float* w, const float* bias, float* partial, int B, int H, int W,
                                 void* stream) {
   MMSA_REQUIRE(x && w && bias && partial && B > 0 && H > 0 && W > 0 && W <= 1024);
-  const size_t sh = (3 * (W + 2) + 8 * 2 * 32) * sizeof(float);
-  hipLaunchKernelGGL(stem_stats_kernel, dim3(B * H), dim3(256), sh, mmsa_stream(stream), x, w, bias, partial, H, W);
+  const int groups = (H + STEM_ROWS - 1) / STEM_ROWS;
+  const size_t sh = ((STEM_ROWS + 2) * (W + 2) + 8 * 2 * 32) * sizeof(float);
+  hipLaunchKernelGGL(stem_stats_kernel, dim3(B * groups), dim3(256), sh, mmsa_stream(stream), x, w, bias, partial, H, W,
+                     groups);
   return mmsa_launch_status();
 }
 

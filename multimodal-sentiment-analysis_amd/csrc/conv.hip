@@ -84,17 +84,37 @@ struct PackDesc {
   int Cout, Cin, ntaps, pad_;
 };
 
-__global__ void pack_weights_multi_kernel(const PackDesc* __restrict__ descs) {
+// Workgroup = a 32 (cout) x 32 (cin) x ntaps tile of one tensor, staged in LDS: the reads are whole runs of 32 * ntaps
+// consecutive floats per cout row, the writes runs of 32 consecutive cin (forward layout) and 32 consecutive cout
+// (data-gradient layout).  blockIdx.x counts the tensor's tiles; workgroups past its tile count leave at once.
+constexpr int PACK_T = 32;
+constexpr int PACK_MAX_TILES = 64;   // per launch row: tensors with more tiles are walked with a stride
+
+__global__ __launch_bounds__(256) void pack_weights_multi_kernel(const PackDesc* __restrict__ descs) {
+  __shared__ float tile[PACK_T][PACK_T * MAX_TAPS + 1];
   const PackDesc d = descs[blockIdx.y];
-  const long total = (long)d.Cout * d.Cin * d.ntaps;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int t = (int)(i % d.ntaps);
-    const long r = i / d.ntaps;
-    const int ci = (int)(r % d.Cin);
-    const int co = (int)(r / d.Cin);
-    const float v = d.w[i];
-    if (d.fwd) d.fwd[((long)t * d.Cout + co) * d.Cin + ci] = v;
-    if (d.dgrad) d.dgrad[((long)t * d.Cin + ci) * d.Cout + co] = v;
+  const int nt = d.ntaps;
+  const int cin_tiles = (d.Cin + PACK_T - 1) / PACK_T, cout_tiles = (d.Cout + PACK_T - 1) / PACK_T;
+  const int t = threadIdx.x;
+  for (int tl = blockIdx.x; tl < cin_tiles * cout_tiles; tl += gridDim.x) {   // uniform
+    const int co0 = (tl / cin_tiles) * PACK_T, ci0 = (tl % cin_tiles) * PACK_T;
+    const int nci = min(PACK_T, d.Cin - ci0), nco = min(PACK_T, d.Cout - co0);
+    const int run = nci * nt;                       // consecutive source floats per cout row
+    for (int r = t >> 6; r < nco; r += 4) {         // one wave per row at a time
+      const float* src = d.w + ((long)(co0 + r) * d.Cin + ci0) * nt;
+      for (int j = t & 63; j < run; j += 64) tile[r][j] = src[j];
+    }
+    __syncthreads();
+    const int c = t & 31;
+    for (int tp = 0; tp < nt; ++tp) {
+      if (d.fwd && c < nci)
+        for (int r = t >> 5; r < nco; r += 8)       // 32 lanes = 32 consecutive cin of one (tap, cout) row
+          d.fwd[((long)tp * d.Cout + co0 + r) * d.Cin + ci0 + c] = tile[r][c * nt + tp];
+      if (d.dgrad && c < nco)
+        for (int ci = t >> 5; ci < nci; ci += 8)    // 32 lanes = 32 consecutive cout of one (tap, cin) row
+          d.dgrad[((long)tp * d.Cin + ci0 + ci) * d.Cout + co0 + c] = tile[c][ci * nt + tp];
+    }
+    __syncthreads();
   }
 }
 
@@ -939,7 +959,7 @@ MMSA_EXPORT int mmsa_conv_pack_desc_bytes() { return (int)sizeof(PackDesc); }
 // descs: DEVICE array of n records {const float* w; float* fwd; float* dgrad; int Cout, Cin, ntaps, pad} (40 bytes each)
 MMSA_EXPORT int mmsa_conv_pack_weights_multi(const void* descs, int n, void* stream) {
   MMSA_REQUIRE(descs && n > 0 && n <= 65535);
-  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(96, n), dim3(256), 0, mmsa_stream(stream),
+  hipLaunchKernelGGL(pack_weights_multi_kernel, dim3(PACK_MAX_TILES, n), dim3(256), 0, mmsa_stream(stream),
                      static_cast<const PackDesc*>(descs));
   return mmsa_launch_status();
 }

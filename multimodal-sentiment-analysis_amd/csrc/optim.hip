@@ -24,9 +24,9 @@ __global__ __launch_bounds__(256) void chunk_sumsq_kernel(const float* __restric
                                                           const long long* __restrict__ chunk_off,
                                                           const int* __restrict__ chunk_len,
                                                           const int* __restrict__ chunk_tensor,
-                                                          double* __restrict__ chunk_ss, int c_first) {
+                                                          double* __restrict__ chunk_ss) {
   __shared__ double red[16];
-  const int c = c_first + blockIdx.x;
+  const int c = blockIdx.x;
   const float* pa = a + chunk_off[c];
   const int n = chunk_len[c];
   float coef = 0.f;
@@ -203,7 +203,21 @@ __global__ void add_scaled_scalar_kernel(float* __restrict__ dst, const float* _
   if (threadIdx.x == 0 && blockIdx.x == 0) dst[0] = a[0] + alpha * b[0];
 }
 
+// diagnostic: the GPU's constant-rate real-time counter (100 MHz) at the moment this one-thread kernel runs
+__global__ void stamp_kernel(unsigned long long* __restrict__ buf, int slot) {
+  buf[slot] = __builtin_amdgcn_s_memrealtime();
+}
+
 }  // namespace
+
+// Diagnostic: buf[slot] <- the GPU's real-time counter (ticks of 10 ns) when the stream reaches this point.  Placed
+// between the launches of a captured sequence it shows when each stream really gets there during an unprofiled
+// replay (a profiler's timeline changes the concurrency it reports on).
+MMSA_EXPORT int mmsa_stamp(unsigned long long* buf, int slot, void* stream) {
+  MMSA_REQUIRE(buf && slot >= 0);
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, mmsa_stream(stream), buf, slot);
+  return mmsa_launch_status();
+}
 
 // Per-tensor L2 norms of the flat buffer `p` -> tnorm[ntensors]; sum of norms -> state[5] (and *sum_out if given).
 MMSA_EXPORT int mmsa_param_norms(const float* p, const long long* chunk_off, const int* chunk_len,
@@ -214,7 +228,7 @@ MMSA_EXPORT int mmsa_param_norms(const float* p, const long long* chunk_off, con
   hipStream_t s = mmsa_stream(stream);
   if (!chunk_sums_ready)   // otherwise chunk_ss already holds the sums (written by the previous mmsa_adamw_step)
     hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, p, (const float*)nullptr,
-                       (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss, 0);
+                       (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss);
   hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors, tnorm,
                      sum_out, (float*)nullptr, StepScalars{});
   return mmsa_launch_status();
@@ -240,41 +254,25 @@ MMSA_EXPORT int mmsa_grad_norm(const float* g, const float* p, const float* tnor
   MMSA_REQUIRE((p == nullptr) == (tnorm == nullptr));
   hipStream_t s = mmsa_stream(stream);
   hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, g, p, tnorm, lambda, chunk_off, chunk_len,
-                     chunk_tensor, chunk_ss, 0);
+                     chunk_tensor, chunk_ss);
   hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors,
                      (float*)nullptr, (float*)nullptr, state + ST_GNORM, StepScalars{});
   return mmsa_launch_status();
 }
 
-// The same norm in two parts, for a backward pass whose gradients become final at different times.
-// mmsa_grad_chunk_sums: the sums of squares of chunks [c_first, c_first + c_count) -> chunk_ss (one launch; call it
-// as soon as those chunks' gradients are final, on any stream).
-MMSA_EXPORT int mmsa_grad_chunk_sums(const float* g, const float* p, const float* tnorm, float lambda,
-                                     const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
-                                     int nchunks, int c_first, int c_count, double* chunk_ss, void* stream) {
-  MMSA_REQUIRE(g && chunk_off && chunk_len && chunk_tensor && chunk_ss);
-  MMSA_REQUIRE((p == nullptr) == (tnorm == nullptr));
-  MMSA_REQUIRE(c_first >= 0 && c_count > 0 && c_first + c_count <= nchunks);
-  hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(c_count), dim3(256), 0, mmsa_stream(stream), g, p, tnorm, lambda, chunk_off,
-                     chunk_len, chunk_tensor, chunk_ss, c_first);
-  return mmsa_launch_status();
-}
-
-// mmsa_grad_norm_finish: the sums of the remaining chunks [0, c_rest) (c_rest may be 0), then the total norm
-// -> state[4] and, in the same launch, the step scalars mmsa_adamw_step would derive (step count + 1, bias corrections,
-// clip coefficient): follow it with mmsa_adamw_step(..., scalars_ready = 1).
+// mmsa_grad_norm that also derives, in its second launch, the step scalars mmsa_adamw_step would derive (step
+// count + 1, bias corrections, clip coefficient): follow it with mmsa_adamw_step(..., scalars_ready = 1).
 MMSA_EXPORT int mmsa_grad_norm_finish(const float* g, const float* p, const float* tnorm, float lambda,
                                       const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
-                                      int nchunks, int c_rest, const int* tensor_first_chunk, int ntensors,
-                                      double* chunk_ss, float* state, float beta1, float beta2, float max_norm,
-                                      int do_clip, void* stream) {
+                                      int nchunks, const int* tensor_first_chunk, int ntensors, double* chunk_ss,
+                                      float* state, float beta1, float beta2, float max_norm, int do_clip,
+                                      void* stream) {
   MMSA_REQUIRE(g && chunk_off && chunk_len && chunk_tensor && tensor_first_chunk && chunk_ss && state);
-  MMSA_REQUIRE(nchunks > 0 && ntensors > 0 && ntensors <= 1024 && c_rest >= 0 && c_rest <= nchunks);
+  MMSA_REQUIRE(nchunks > 0 && ntensors > 0 && ntensors <= 1024);
   MMSA_REQUIRE((p == nullptr) == (tnorm == nullptr));
   hipStream_t s = mmsa_stream(stream);
-  if (c_rest > 0)
-    hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(c_rest), dim3(256), 0, s, g, p, tnorm, lambda, chunk_off, chunk_len,
-                       chunk_tensor, chunk_ss, 0);
+  hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, g, p, tnorm, lambda, chunk_off, chunk_len,
+                     chunk_tensor, chunk_ss);
   hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors,
                      (float*)nullptr, (float*)nullptr, state + ST_GNORM,
                      StepScalars{state, beta1, beta2, max_norm, do_clip});

@@ -33,7 +33,6 @@ class ChunkTable:
                 pos += c
         first.append(len(off))
         self.nchunks = len(off)
-        self.first_chunk_host = list(first)            # first chunk of every tensor (and the end), on the host
         self.ntensors = len(sizes)
         self.chunk_off = torch.tensor(off, dtype=torch.int64, device=device)
         self.chunk_len = torch.tensor(ln, dtype=torch.int32, device=device)

@@ -237,16 +237,20 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
         def wgrad_conv1_shortcut():
             ops.conv_wgrad_pair(s.a_in, d_c1, gw1, d_sc, gws, wg, wgs, B, H, W, Cin, Cout)
 
+    ops.stamp(name + ".main.dc2_ready")
     f2 = fork(ws, d_out.device, enable=FORK_WGRAD).mark()           # d_c2 / d_sc are ready
     ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
     if deferred is not None:
         deferred.append(wgrad_conv2)
     else:
         with f2:
+            ops.stamp(name + ".side.wgrad2_start")
             wgrad_conv2()
+            ops.stamp(name + ".side.wgrad2_end")
     sc2 = ws.buf(name + ".bnrelu_scratch", ops.bn_relu_bwd_scratch(B * H * W, Cout))
     ops.bn_relu_bwd(d_h1, s.c1, s.coeff1, grads.of(blk.bn1.weight), grads.of(blk.bn1.bias), sc2, B * H * W, Cout,
                     training)
+    ops.stamp(name + ".main.dc1_ready")
     f1 = fork(ws, d_out.device, enable=FORK_WGRAD).mark()           # d_c1 is ready
     if need_dx:
         # 3x3 branch and 1x1 shortcut in one launch (one K loop over both operand pairs); on a map with few output
@@ -259,7 +263,9 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
         deferred.append(wgrad_conv1_shortcut)
     else:
         with f1:
+            ops.stamp(name + ".side.wgrad1_start")
             wgrad_conv1_shortcut()
+            ops.stamp(name + ".side.wgrad1_end")
     return d_in
 
 
@@ -284,10 +290,11 @@ def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Works
     # point fixed here)
     fpack = fork(ws, x.device).mark()
     partial = None
+    srows = ops.stem_stats_rows(B, H)
     if training:
-        partial = ws.buf("stem.partial", B * H * 64)
+        partial = ws.buf("stem.partial", srows * 64)
         ops.stem_stats(x, conv0.weight, conv0.bias, partial, B, H, W)
-    ops.bn_finalize(partial, B * H, H, B * H * W, g, b, rm, rv, nbt, training, st.coeff0, None, 32)
+    ops.bn_finalize(partial, srows, srows // B, B * H * W, g, b, rm, rv, nbt, training, st.coeff0, None, 32)
     a = ws.buf("stem.out", (B, H // 2, W // 2, 32))
     ops.stem_apply_pool(x, conv0.weight, conv0.bias, st.coeff0, a, B, H, W)
     h, w, cin = H // 2, W // 2, 32
@@ -301,11 +308,13 @@ def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Works
                     ws.buf(f"rb{i + 1}.d_in", (B, hh, ww, cc)).zero_()
                 hh, ww, cc = hh // 2, ww // 2, cc * 2
     fpack.join()
+    ops.stamp("fwd.stem_done")
     for i, blk in enumerate((m.res_block1, m.res_block2, m.res_block3)):
         cout = blk.conv1.weight.shape[0]
         s = block_forward(blk, f"rb{i + 1}", a, B, h, w, cin, cout, training, need_grad, ws, packs)
         st.blocks.append(s)
         a, h, w, cin = s.out, h // 2, w // 2, cout
+        ops.stamp(f"fwd.rb{i + 1}_done")
     st.P, st.C = h * w, cin
     feat = ws.buf("audio.feat", (B, cin))
     ops.gap_fwd(a, feat, B, st.P, cin)
@@ -338,4 +347,6 @@ def audio_backward(m, st, dfeat: torch.Tensor, training: bool, grads: Grads, ws:
                 ws.objs["audio.reduceplan"] = plan
         with fork(ws, dfeat.device, enable=FORK_WGRAD):
             plan.run(reduce_list)
+    ops.stamp("audio_bwd.main.chain_end")
     fork(ws, dfeat.device).join()                # all weight gradients are in
+    ops.stamp("audio_bwd.main.joined")

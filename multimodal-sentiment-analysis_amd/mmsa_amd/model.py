@@ -547,25 +547,20 @@ class MultimodalSentimentModel(nn.Module):
             run.touched = {id(p) for p in self.parameters()}
         return run
 
-    def _backward(self, run, dlogits, grads: Grads, ws: Optional[Workspace] = None, phase: str = "all",
-                  after_early=None):
+    def _backward(self, run, dlogits, grads: Grads, ws: Optional[Workspace] = None, phase: str = "all"):
         """``phase`` splits the 'both' backward for data-parallel runs: "early" = head + text branch (their gradients,
-        87 % of the bytes, can be exchanged while the rest runs), "late" = audio branch.  ``after_early`` (phase "all",
-        modality 'both'): a pair of callables, the first enqueued behind the text branch's backward on its helper
-        stream, the second behind the head's parameter gradients on theirs (both beside the audio branch's backward)."""
+        87 % of the bytes, can be exchanged while the rest runs), "late" = audio branch."""
         ws = ws or Workspace(dlogits.device, persistent=False)
         if phase != "all" and self.modality != "both":
             raise ValueError("the split backward exists for modality 'both' only")
         dev = dlogits.device if dlogits is not None else self._arena.device
 
-        def side_work(then=None):
+        def side_work():
             """Everything that only the optimiser or the caller reads: the head's parameter gradients, then the loss
             values, on helper stream 2."""
             for fn in getattr(run.head, "side_work", []):
                 fn()
-            deferred = list(getattr(run.head, "deferred", []))
-            if then is not None:
-                deferred.append(then)
+            deferred = getattr(run.head, "deferred", [])
             if deferred:
                 with audio_engine.fork(ws, dev, 2):
                     for fn in deferred:
@@ -583,13 +578,12 @@ class MultimodalSentimentModel(nn.Module):
             return
         if self.modality == "both":
             d_a, d_t = head_engine.head_backward_both(self, run.head, dlogits, grads, ws)
+            ops.stamp("bwd.head_done")
             # launch order matters under graph replay: the short text branch and the side work are enqueued first (they
             # then start at once on helper queues), the audio chain after them
             with audio_engine.fork(ws, dev, 1) as f:
                 text_engine.text_backward(self.text_model, run.text, d_t, grads)
-                if after_early is not None:
-                    after_early[0]()
-            side_work(after_early[1] if after_early is not None else None)
+            side_work()
             audio_engine.audio_backward(self.audio_model, run.audio, d_a, self.audio_model.training, grads, ws)
             f.join()
         elif self.modality == "audio":

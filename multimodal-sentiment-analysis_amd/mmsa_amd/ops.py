@@ -214,6 +214,8 @@ class PackPlan:
                 _chk(w)
                 cout, cin = w.shape[0], w.shape[1]
                 ntaps = w.numel() // (cout * cin)
+                if not 1 <= ntaps <= 9:
+                    raise ValueError("pack: a convolution weight has 1 to 9 taps")
                 for x in (f, d):
                     if x is not None and (x.numel() != w.numel() or _chk(x) == 0):
                         raise ValueError("packed buffer size mismatch")
@@ -419,8 +421,14 @@ class ReducePlan:
 
 
 # ---------------------------------------------------------------------------------------------- audio branch
+def stem_stats_rows(B, H) -> int:
+    """Rows of the stem's statistics table (one per group of image rows): ``partial`` holds 64 floats per row."""
+    return _lib.query("mmsa_stem_stats_rows", B, H)
+
+
 def stem_stats(x, w, bias, partial, B, H, W):
-    if x.numel() != B * H * W or partial.numel() != B * H * 64 or w.numel() != 288 or bias.numel() != 32:
+    if (x.numel() != B * H * W or partial.numel() != stem_stats_rows(B, H) * 64 or w.numel() != 288
+            or bias.numel() != 32):
         raise ValueError("stem_stats: bad sizes")
     _lib.call("mmsa_stem_stats", _chk(x), _chk(w), _chk(bias), _chk(partial), B, H, W, _stream())
 
@@ -825,19 +833,12 @@ def grad_norm(gflat, table, state, pflat=None, tnorm=None, lam=0.0):
               _chk(state), _stream())
 
 
-def grad_chunk_sums(gflat, table, c_first, c_count, pflat=None, tnorm=None, lam=0.0):
-    """First part of :func:`grad_norm` taken early: the sums of squares of chunks [c_first, c_first + c_count)."""
-    _lib.call("mmsa_grad_chunk_sums", _chk(gflat), _opt(pflat), _opt(tnorm), float(lam), _chk(table.chunk_off, torch.int64),
-              _chk(table.chunk_len, torch.int32), _chk(table.chunk_tensor, torch.int32), table.nchunks, int(c_first),
-              int(c_count), _chk(table.chunk_ss, torch.float64), _stream())
-
-
-def grad_norm_finish(gflat, table, state, c_rest, beta1, beta2, max_norm, do_clip, pflat=None, tnorm=None, lam=0.0):
-    """Second part: the sums of chunks [0, c_rest), the total norm -> state[4], and the step's scalars (step count,
-    bias corrections, clip coefficient) in the same launch; :func:`adamw_step` then takes ``scalars_ready=True``."""
+def grad_norm_finish(gflat, table, state, beta1, beta2, max_norm, do_clip, pflat=None, tnorm=None, lam=0.0):
+    """:func:`grad_norm` that also derives the step's scalars (step count, bias corrections, clip coefficient) in its
+    second launch; :func:`adamw_step` then takes ``scalars_ready=True``."""
     _lib.call("mmsa_grad_norm_finish", _chk(gflat), _opt(pflat), _opt(tnorm), float(lam),
               _chk(table.chunk_off, torch.int64), _chk(table.chunk_len, torch.int32),
-              _chk(table.chunk_tensor, torch.int32), table.nchunks, int(c_rest),
+              _chk(table.chunk_tensor, torch.int32), table.nchunks,
               _chk(table.tensor_first_chunk, torch.int32), table.ntensors, _chk(table.chunk_ss, torch.float64),
               _chk(state), float(beta1), float(beta2), float(max_norm), int(do_clip), _stream())
 
@@ -852,6 +853,21 @@ def adamw_step(p, g, m, v, table, state, lr, beta1, beta2, eps, wd, max_norm, do
               float(lam), _chk(state), float(lr), float(beta1), float(beta2), float(eps), float(wd), float(max_norm),
               int(do_clip), _chk(table.chunk_ss_p, torch.float64) if emit_param_sums else None, int(scalars_ready),
               _stream())
+
+
+# Diagnostic time stamps (tools/step_stamps.py): STAMPS = (int64 device buffer, {label: slot}) switches them on.
+STAMPS = None
+
+
+def stamp(label: str):
+    """Records the GPU's real-time counter when the current stream reaches this point (no-op unless STAMPS is set)."""
+    if STAMPS is None:
+        return
+    buf, slots = STAMPS
+    slot = slots.setdefault(label, len(slots))
+    if slot >= buf.numel():
+        raise ValueError("stamp buffer too small")
+    _lib.call("mmsa_stamp", _chk(buf, torch.int64), slot, _stream())
 
 
 def scale_by_state(g, state, idx):

@@ -113,16 +113,6 @@ class TrainStep:
             dense_from = self.arena.offsets[n_audio + 1] if self._use_sparse else split
             self._early_buckets = [(dense_from + lo, dense_from + hi) for lo, hi in
                                    parallel.make_buckets(self.g.numel() - dense_from, bucket)]
-        # One GPU, modality 'both': the head's and the text branch's gradients (87 % of the bytes) are final long before
-        # the audio branch's; their share of the clip norm is summed beside the audio backward (chunks from here on)
-        self._c_split = None
-        if (not self.dist and model.modality == "both" and max_norm is not None
-                and os.environ.get("MMSA_EARLY_SUMS", "1") == "1"):
-            n_audio = len(list(model.audio_model.parameters()))
-            n_text = len(list(model.text_model.parameters()))
-            self._c_split = self.arena.table.first_chunk_host[n_audio]
-            self._c_head = self.arena.table.first_chunk_host[n_audio + n_text]
-        self._early_sums_done = False
         from .head import _use_layers
         if use_graph and model.training and model._drop_p() > 0 and (model.modality != "both" or _use_layers()):
             # the fused 'both' head mixes the device-resident step count into its dropout seed; the layer-by-layer
@@ -139,9 +129,11 @@ class TrainStep:
         if phase == "late":
             model._backward(self._run, None, self.grads, self.ws, phase="late")
             return self._run.l2
+        ops.stamp("step.start")
         if wave is not None:
             audio = self.ws.buf("step.spec", (wave.shape[0], 1, 64, 130))
             self.frontend(wave, out=audio)
+            ops.stamp("fwd.frontend_done")
         pre_zero = phase == "early"
         if pre_zero:
             # the embedding-gradient table is cleared beside the forward pass instead of ahead of the text backward,
@@ -153,20 +145,11 @@ class TrainStep:
                          grad_scale=1.0 / self.world, step_state=self.state[0:1])
         if pre_zero:
             run.text.dtable_zeroed = True
+        ops.stamp("step.forward_done")
         d = run.head.dlogits
         if self.world > 1 and not getattr(run.head, "grad_scaled", False):
             d.mul_(1.0 / self.world)            # sum over ranks of per-rank means -> global mean
-        self._early_sums_done = False
-        hook = None
-        if self._c_split is not None and phase == "all":
-            def sums(c0, c1):
-                a = self.arena
-                ops.grad_chunk_sums(self.g, a.table, c0, c1 - c0, a.flat if run.l2 else None,
-                                    a.tnorm if run.l2 else None, L2_LAMBDA if run.l2 else 0.0)
-                self._early_sums_done = True
-            c_text, c_head, c_end = self._c_split, self._c_head, self.arena.table.nchunks
-            hook = (lambda: sums(c_text, c_head), lambda: sums(c_head, c_end))
-        model._backward(run, d, self.grads, self.ws, phase=phase, after_early=hook)
+        model._backward(run, d, self.grads, self.ws, phase=phase)
         self._run = run
         self.loss = run.loss
         self.logits = run.head.logits
@@ -231,19 +214,17 @@ class TrainStep:
         a = self.arena
         do_clip = self.max_norm is not None
         tn, lam = (a.tnorm, L2_LAMBDA) if l2 else (None, 0.0)
-        early = do_clip and (self._early_sums_done or os.environ.get("MMSA_EARLY_SUMS") == "fuse")
-        if early:
-            ops.grad_norm_finish(self.g, a.table, self.state,
-                                 self._c_split if self._early_sums_done else a.table.nchunks, self.betas[0],
-                                 self.betas[1], self.max_norm, True, a.flat if l2 else None, tn, lam)
-        elif do_clip:
-            ops.grad_norm(self.g, a.table, self.state, a.flat if l2 else None, tn, lam)
+        ops.stamp("step.backward_done")
+        if do_clip:      # the norm kernel's second launch also advances the step count and derives the clip coefficient
+            ops.grad_norm_finish(self.g, a.table, self.state, self.betas[0], self.betas[1], self.max_norm, True,
+                                 a.flat if l2 else None, tn, lam)
         # AdamW also leaves the per-chunk sums of squares of the UPDATED parameters behind: the next step's
         # regulariser norms need no pass of their own over the 38 MB parameter buffer
         ops.adamw_step(a.flat, self.g, self.m, self.v, a.table, self.state, self.lr, self.betas[0], self.betas[1],
                        self.eps, self.wd, self.max_norm if do_clip else 0.0, do_clip, tn, lam, emit_param_sums=l2,
-                       scalars_ready=early)
+                       scalars_ready=do_clip)
         self._norms_ready = l2
+        ops.stamp("step.end")
 
     @staticmethod
     def _copy_inputs(pending):

@@ -207,6 +207,29 @@ GEOMS = [(3, 32, 65, 32, 64), (3, 32, 65, 64, 64), (2, 16, 32, 64, 128), (2, 16,
          (2, 8, 16, 128, 256), (2, 8, 16, 256, 256), (32, 8, 16, 128, 256), (40, 16, 32, 64, 128)]
 
 
+def test_weight_table_repack_is_a_permutation():
+    """One launch re-lays-out a table of weight tensors (LDS-tiled): [Cout][Cin][taps] -> [tap][Cout][Cin] and
+    [tap][Cin][Cout], bit for bit, for tile-aligned and ragged shapes, 1 to 9 taps, either output optional."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(256, 256, 9), (64, 32, 9), (64, 32, 1), (128, 256, 5), (128, 256, 4), (128, 256, 3), (40, 48, 9),
+              (33, 31, 2), (96, 500, 3)]
+    triples, refs = [], []
+    for i, (co, ci, nt) in enumerate(shapes):
+        w = torch.randn(co, ci, nt, generator=g).to(DEV)
+        f = torch.full((w.numel(),), float("nan"), device=DEV) if i != 2 else None
+        d = torch.full((w.numel(),), float("nan"), device=DEV) if i != 4 else None
+        triples.append((w, f, d))
+        refs.append((w.permute(2, 0, 1).contiguous().flatten(), w.permute(2, 1, 0).contiguous().flatten()))
+    ops.PackPlan().run(triples)
+    torch.cuda.synchronize()
+    for (w, f, d), (rf, rd) in zip(triples, refs):
+        assert f is None or torch.equal(f, rf), tuple(w.shape)
+        assert d is None or torch.equal(d, rd), tuple(w.shape)
+    with pytest.raises(ValueError):
+        ops.PackPlan().run([(torch.zeros(4, 4, 10, device=DEV), torch.zeros(160, device=DEV), None)])
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", GEOMS)
 def test_conv3x3_forward_and_stats(B, H, W, Cin, Cout):
     ops = _ops()
