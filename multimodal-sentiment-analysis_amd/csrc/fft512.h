@@ -58,3 +58,46 @@ __device__ __forceinline__ void fft512(float2 (&v)[8], float2* __restrict__ fa, 
   for (int r = 0; r < 8; ++r) fa[j + 64 * r] = v[r];
   __syncthreads();
 }
+
+// The same transform for a wavefront on its own: one LDS row, used in place, and no workgroup barrier.  A wavefront's
+// LDS instructions execute in issue order, so every lane's reads of a pass are served before any lane's writes of
+// that pass reach the row, and the next pass's reads see all of them; the fences only keep the compiler from
+// moving LDS accesses across the pass boundaries.  `twh[m]` = e^{-2 pi i m / 512} for m < 256 (the second half of
+// the circle is the negated first half).  On return row[n] = Z[n], n = 0..511, in natural order.
+__device__ __forceinline__ float2 fft512_tw(const float2* __restrict__ twh, int m) {
+  const float2 w = twh[m & 255];
+  return (m & 256) ? make_float2(-w.x, -w.y) : w;
+}
+
+__device__ __forceinline__ void fft512_wave(float2 (&v)[8], float2* row, const float2* __restrict__ twh, int j) {
+  dft8(v);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) row[j * 9 + r] = v[r];            // element i lives at i + i / 8
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  {
+    const int k = j & 7;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float2 x = row[j + (j >> 3) + 72 * r];
+      const float2 tw = fft512_tw(twh, r * k * 8);
+      v[r] = make_float2(x.x * tw.x - x.y * tw.y, x.x * tw.y + x.y * tw.x);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // all reads of the row are issued before the writes
+    dft8(v);
+    const int j0 = (j >> 3) * 72 + k;                           // element i lives at i + 8 * (i / 64)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) row[j0 + 8 * r] = v[r];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const float2 x = row[j + 72 * r];
+    const float2 tw = fft512_tw(twh, r * j);
+    v[r] = make_float2(x.x * tw.x - x.y * tw.y, x.x * tw.y + x.y * tw.x);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  dft8(v);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) row[j + 64 * r] = v[r];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}

@@ -22,11 +22,13 @@ constexpr int NBINS = 513;
 constexpr int NMEL = 64;
 constexpr int FPB = 4;  // frames per workgroup: 64 threads each
 
-// One workgroup = FPB consecutive frames of one utterance, 64 threads per frame.  The 1024 real samples of a frame
-// are windowed and packed as a 512-point complex sequence, transformed by a radix-8 Stockham FFT (three passes with
-// an 8-point DFT in registers: three barriers instead of the nine of a radix-2 transform), unpacked to the 513
-// one-sided power bins, multiplied by the (sparse, triangular) mel filterbank and converted to dB.
-__global__ __launch_bounds__(256) void logmel_db_kernel(
+// One workgroup = FPB consecutive frames of one utterance, one wavefront per frame.  After the group's samples are
+// staged (one barrier), every wavefront runs on its own: it windows its frame, packs the 1024 real samples as a
+// 512-point complex sequence, transforms it in place in its LDS row (radix-8 Stockham, 8-point DFTs in registers, no
+// workgroup barrier: fft512_wave) and unpacks the 513 one-sided power bins into the same row.  A second barrier, then
+// the (sparse, triangular) mel filterbank over all frames of the group and the conversion to dB.  30 KiB of LDS per
+// workgroup, so five workgroups share a CU.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void logmel_db_kernel(
     const float* __restrict__ wave, long wave_stride, int n_valid, int n_target, int n_frames,
     const float* __restrict__ window,   // [1024]
     const float* __restrict__ tw512,    // [256][2]  cos, -sin of 2*pi*j/512
@@ -35,22 +37,17 @@ __global__ __launch_bounds__(256) void logmel_db_kernel(
     const int* __restrict__ melrange,   // [64][2]   first bin, one-past-last bin with non-zero weight
     float* __restrict__ out)            // [B][64][n_frames] dB
 {
+  // seg: the group's reflect-padded samples; once every wavefront has consumed them (second barrier) the dB values
+  // of the group are collected in the same memory
   __shared__ float seg[(FPB + 1) * HOP];
-  // the two FFT buffers are padded (one element per 8 in fa's first use, 8 per 64 in fb) so that the strided stores
-  // of the first two passes spread over the LDS banks; the power spectrum reuses fb once the transform is done
-  __shared__ float2 fa[FPB][576];
-  __shared__ float2 fb[FPB][576];
-  __shared__ float dbv[NMEL][FPB + 1];
-  float (*power)[NBINS + 3] = reinterpret_cast<float (*)[NBINS + 3]>(&fb[0][0]);
-  static_assert(sizeof(float) * FPB * (NBINS + 3) <= sizeof(float2) * FPB * 576, "power must fit in fb");
-  __shared__ float2 tws[512];   // e^{-2 pi i m / 512}
+  __shared__ float2 rows[FPB][FFT512_LD];   // per frame: FFT work row (padded), then its power spectrum
+  __shared__ float2 twh[256];               // e^{-2 pi i m / 512}, m < 256
+  static_assert(sizeof(float) * (NBINS + 3) <= sizeof(float2) * FFT512_LD, "the power spectrum must fit in the row");
+  static_assert(NMEL * (FPB + 1) <= (FPB + 1) * HOP, "the dB values must fit in the sample buffer");
+  float (*dbv)[FPB + 1] = reinterpret_cast<float (*)[FPB + 1]>(seg);
 
   const int t = threadIdx.x;
-  {
-    const float2 w = make_float2(tw512[2 * t], tw512[2 * t + 1]);
-    tws[t] = w;
-    tws[t + 256] = make_float2(-w.x, -w.y);
-  }
+  twh[t] = make_float2(tw512[2 * t], tw512[2 * t + 1]);
   const int b = blockIdx.y;
   const int f0 = blockIdx.x * FPB;
   const float* w = wave + (long)b * wave_stride;
@@ -58,18 +55,14 @@ __global__ __launch_bounds__(256) void logmel_db_kernel(
 
   // Constants this thread will need later are requested now, so that their memory latency passes behind the staging
   // and the transform: its window pair per packed sample, the unpack twiddles of its bins, its mel weights.
-  constexpr int UNP = (FPB * NBINS + 255) / 256;   // unpack items per thread
-  constexpr int MW = 16;                           // mel weights held in registers per lane (rest: read on demand)
+  constexpr int UNP = (NBINS + 63) / 64;           // unpack items per lane: bins j, j + 64, ..., 512 (lane 0 only)
+  constexpr int MW = 12;                           // mel weights held in registers per lane (rest: read on demand)
   float2 wv[8], utw[UNP];
   float mwt[MW];
 #pragma unroll
   for (int r = 0; r < 8; ++r) wv[r] = *reinterpret_cast<const float2*>(window + 2 * (j + 64 * r));
 #pragma unroll
-  for (int u = 0; u < UNP; ++u) {
-    const int i = t + 256 * u;
-    const int k = i < FPB * NBINS ? i % NBINS : 0;
-    utw[u] = *reinterpret_cast<const float2*>(tw1024 + 2 * k);
-  }
+  for (int u = 0; u < UNP; ++u) utw[u] = *reinterpret_cast<const float2*>(tw1024 + 2 * min(j + 64 * u, NBINS - 1));
   const int mel_m = t >> 2, mel_q = t & 3;
   const int mel_lo = melrange[2 * mel_m], mel_hi = melrange[2 * mel_m + 1];
 #pragma unroll
@@ -89,64 +82,43 @@ __global__ __launch_bounds__(256) void logmel_db_kernel(
   }
   __syncthreads();
 
-  float2 v[8];
-  // pass 1 (sub-transform length 1): inputs straight from the windowed samples, z[n] = (x[2n], x[2n+1]) * window
+  float2* row = rows[fi];
   {
+    float2 v[8];
+    // z[n] = (x[2n], x[2n+1]) * window
     const float* sgm = seg + fi * HOP;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const int n = j + 64 * r;
       v[r] = make_float2(sgm[2 * n] * wv[r].x, sgm[2 * n + 1] * wv[r].y);
     }
-    dft8(v);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) fa[fi][j * 9 + r] = v[r];   // element i lives at i + i / 8
+    fft512_wave(v, row, twh, j);
   }
-  __syncthreads();
-  // pass 2 (sub-transform length 8)
+  // unpack the real-input spectrum: X[k] = (Z[k]+conj(Z[512-k]))/2 + W^k (Z[k]-conj(Z[512-k]))/(2i).  The power
+  // values go into the row the spectrum is read from, so every lane first takes all its pairs.
   {
-    const int k = j & 7;
+    float2 zk[UNP], zc[UNP];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float2 x = fa[fi][j + (j >> 3) + 72 * r];
-      const float2 tw = tws[r * k * 8];
-      v[r] = make_float2(x.x * tw.x - x.y * tw.y, x.x * tw.y + x.y * tw.x);
+    for (int u = 0; u < UNP; ++u) {
+      const int k = min(j + 64 * u, NBINS - 1);
+      zk[u] = row[k & 511];
+      zc[u] = row[(512 - k) & 511];
     }
-    dft8(v);
-    const int j0 = (j >> 3) * 72 + k;                         // element i lives at i + 8 * (i / 64)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float* power = reinterpret_cast<float*>(row);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) fb[fi][j0 + 8 * r] = v[r];
-  }
-  __syncthreads();
-  // pass 3 (sub-transform length 64)
-  {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const float2 x = fb[fi][j + 72 * r];
-      const float2 tw = tws[r * j];
-      v[r] = make_float2(x.x * tw.x - x.y * tw.y, x.x * tw.y + x.y * tw.x);
+    for (int u = 0; u < UNP; ++u) {
+      const int k = j + 64 * u;
+      if (k >= NBINS) break;
+      const float er = 0.5f * (zk[u].x + zc[u].x), ei = 0.5f * (zk[u].y - zc[u].y);   // even part
+      const float dr = 0.5f * (zk[u].x - zc[u].x), di = 0.5f * (zk[u].y + zc[u].y);   // (Z - conj Z')/2
+      // odd part = (dr + i di) / i = di - i dr
+      const float orr = di, oi = -dr;
+      const float c = utw[u].x, sn = utw[u].y;
+      const float xr = er + (orr * c - oi * sn);
+      const float xi = ei + (orr * sn + oi * c);
+      power[k] = xr * xr + xi * xi;
     }
-    dft8(v);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) fa[fi][j + 64 * r] = v[r];
-  }
-  __syncthreads();
-  // unpack the real-input spectrum: X[k] = (Z[k]+conj(Z[512-k]))/2 + W^k (Z[k]-conj(Z[512-k]))/(2i)
-#pragma unroll
-  for (int u = 0; u < UNP; ++u) {
-    const int i = t + 256 * u;
-    if (i >= FPB * NBINS) break;
-    const int f = i / NBINS, k = i - f * NBINS;
-    const float2 zk = fa[f][k & 511];
-    const float2 zc = fa[f][(512 - k) & 511];
-    const float er = 0.5f * (zk.x + zc.x), ei = 0.5f * (zk.y - zc.y);   // even part
-    const float dr = 0.5f * (zk.x - zc.x), di = 0.5f * (zk.y + zc.y);   // (Z - conj Z')/2
-    // odd part = (dr + i di) / i = di - i dr
-    const float orr = di, oi = -dr;
-    const float c = utw[u].x, sn = utw[u].y;
-    const float xr = er + (orr * c - oi * sn);
-    const float xi = ei + (orr * sn + oi * c);
-    power[f][k] = xr * xr + xi * xi;
   }
   __syncthreads();
   // mel: 4 lanes per filter; each filter weight is fetched once and applied to all frames of the group, then dB
@@ -155,18 +127,19 @@ __global__ __launch_bounds__(256) void logmel_db_kernel(
     float acc[FPB];
 #pragma unroll
     for (int f = 0; f < FPB; ++f) acc[f] = 0.f;
+    auto power = [&](int f, int bin) { return reinterpret_cast<const float*>(rows[f])[bin]; };
 #pragma unroll
     for (int u = 0; u < MW; ++u) {
       const int bin = mel_lo + q + 4 * u;
       if (bin < mel_hi) {
 #pragma unroll
-        for (int f = 0; f < FPB; ++f) acc[f] = fmaf(mwt[u], power[f][bin], acc[f]);
+        for (int f = 0; f < FPB; ++f) acc[f] = fmaf(mwt[u], power(f, bin), acc[f]);
       }
     }
     for (int bin = mel_lo + q + 4 * MW; bin < mel_hi; bin += 4) {   // filters wider than 4 * MW bins
       const float wgt = melfb[bin * NMEL + m];
 #pragma unroll
-      for (int f = 0; f < FPB; ++f) acc[f] = fmaf(wgt, power[f][bin], acc[f]);
+      for (int f = 0; f < FPB; ++f) acc[f] = fmaf(wgt, power(f, bin), acc[f]);
     }
 #pragma unroll
     for (int f = 0; f < FPB; ++f) {

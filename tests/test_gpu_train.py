@@ -198,10 +198,13 @@ def test_graph_replay_equals_eager():
         res.append((torch.stack(ls).cpu(), m._arena.flat.clone().cpu()))
     # same kernels, same order; the only run-to-run freedom is the order of the float atomic adds that scatter
     # repeated tokens' embedding gradients, so agreement is to rounding, not bitwise
-    # (Adam then turns a last-bit difference in a noise-level gradient into a different +-lr step for that element)
-    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-4
+    # (Adam then turns a last-bit difference in a noise-level gradient into a different +-lr step for that element, and
+    # the difference grows 5-25x per step: measured between two runs of one configuration up to 1.5e-4 in the sixth
+    # loss.  The first three steps are held to rounding, the rest to a bound on that drift.)
+    dl = (res[0][0] - res[1][0]).abs().flatten()
+    assert float(dl[:3].max()) < 2e-6 and float(dl.max()) < 1e-3, dl
     diff = float(torch.linalg.vector_norm(res[0][1] - res[1][1]))
-    assert diff < 1e-3 * float(torch.linalg.vector_norm(res[0][1])), diff
+    assert diff < 3e-3 * float(torch.linalg.vector_norm(res[0][1])), diff
 
 
 def test_train_from_waveforms_uses_frontend():
@@ -274,10 +277,11 @@ def test_single_rank_process_group_path_equals_plain_step(overlap, monkeypatch):
             ts, l_dist, p_dist = run(dict(use_graph=use_graph))
             assert ts.dist and ts.overlap == (overlap == "1")
             # run-to-run freedom: the order of the float atomic adds of repeated tokens' embedding gradients,
-            # amplified by Adam over six steps
-            assert float((l_plain - l_dist).abs().max()) < 1e-4
+            # amplified by Adam over six steps (see test_graph_replay_equals_eager)
+            dl = (l_plain - l_dist).abs().flatten()
+            assert float(dl[:3].max()) < 2e-6 and float(dl.max()) < 1e-3, dl
             diff = float(torch.linalg.vector_norm(p_plain - p_dist))
-            assert diff < 1e-3 * float(torch.linalg.vector_norm(p_plain)), diff
+            assert diff < 3e-3 * float(torch.linalg.vector_norm(p_plain)), diff
     finally:
         dist.destroy_process_group()
 
