@@ -160,6 +160,11 @@ def kernel_roofline(args, ts, model, fe, batches, use_graph, distributed):
 
 def main():
     args = parse()
+    # stdout carries exactly one line, the JSON record: whatever libraries print there (RCCL's version banner does,
+    # when a process group is created) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -252,7 +257,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -105,11 +105,12 @@ class TrainStep:
             self._late_buckets = parallel.make_buckets(split, bucket)
             # The embedding table is the first tensor behind the audio branch and 81 % of all gradient bytes, but a
             # batch touches at most B * L of its 30 522 rows: exchanged as (ids, rows) its traffic is 4 MiB sent and
-            # (world - 1) x 4 MiB received per rank instead of a 31 MB all-reduce.  MMSA_SPARSE_EMB=1 / 0 forces the
-            # row-sparse exchange on / off; by default it is used up to four ranks (at eight, what a rank receives is
-            # only half of a ring all-reduce's traffic, and the exchange ends with world index-add launches).
-            want_sp = os.environ.get("MMSA_SPARSE_EMB", "auto")
-            self._use_sparse = want_sp == "1" or (want_sp != "0" and 1 < self.world <= 4)
+            # (world - 1) x 4 MiB received per rank instead of a 31 MB all-reduce.  Off unless MMSA_SPARSE_EMB=1: the
+            # dense exchange already runs underneath the audio backward, while the sparse one is a chain of a dozen
+            # small host-issued launches (sort, gather, two all-gathers, zero, ordered adds: 0.18 ms on its helper
+            # stream) that cost 0.28 ms per step in a one-rank run (1.77 vs 1.49 ms); it pays only where the dense
+            # exchange cannot be hidden (slow links, many ranks per link).
+            self._use_sparse = os.environ.get("MMSA_SPARSE_EMB", "0") == "1"
             dense_from = self.arena.offsets[n_audio + 1] if self._use_sparse else split
             self._early_buckets = [(dense_from + lo, dense_from + hi) for lo, hi in
                                    parallel.make_buckets(self.g.numel() - dense_from, bucket)]
@@ -183,18 +184,20 @@ class TrainStep:
             if self._sparse is None or self._sparse.n != ids.numel():
                 self._sparse = parallel.SparseRowExchange(ids.numel(), emb.shape[1], emb.shape[0], self.arena.device,
                                                           self.pg)
-            self._sparse.pack(dtable, ids)
-            sp = self._sparse.start()
             from .audio import FORK_ANY, side_stream
             self._sparse_pending = None
             if FORK_ANY and dtable.is_cuda and dist_backend_is_stream_ordered(self.pg):
+                # the whole exchange (pack, two all-gathers, zero + ordered adds) on a helper stream behind the early
+                # backward: nothing of it sits between the early and the late part of the step
                 helper = side_stream(self.arena.device, 3)
                 helper.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(helper):
-                    self._sparse.finish(dtable, sp)
+                    self._sparse.pack(dtable, ids)
+                    self._sparse.finish(dtable, self._sparse.start())
                 self._sparse_pending = helper
             else:
-                self._sparse_pending = (dtable, sp)
+                self._sparse.pack(dtable, ids)
+                self._sparse_pending = (dtable, self._sparse.start())
         return handles
 
     def _allreduce_late(self, early):

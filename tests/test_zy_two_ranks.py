@@ -63,9 +63,9 @@ def test_row_sparse_and_dense_embedding_exchange_agree(tmp_path):
 def test_two_ranks_sharing_one_gpu(use_graph, tmp_path):
     """Two data-parallel ranks (gloo over GPU tensors, both on this GPU) against a single-process emulation: per step
     the gradient is the mean of the two ranks' autograd gradients (each already holds the regulariser's gradient
-    once), clipped at 1.0 and applied by torch.optim.AdamW.  Replicas must stay bit-identical to each other.  At two
-    ranks the embedding table's gradient travels row-sparse."""
-    r0, r1 = _run_two_ranks(use_graph, str(tmp_path / "dp"), 29800)
+    once), clipped at 1.0 and applied by torch.optim.AdamW.  Replicas must stay bit-identical to each other.  The
+    embedding table's gradient travels row-sparse here (MMSA_SPARSE_EMB=1), so both exchanges are under test."""
+    r0, r1 = _run_two_ranks(use_graph, str(tmp_path / "dp"), 29800, MMSA_SPARSE_EMB="1")
     assert r0["sparse"] is True
 
     m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
