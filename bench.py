@@ -102,7 +102,8 @@ def kernel_roofline(args, ts, model, fe, batches, use_graph, distributed):
     """Roofline object of the dominant kernel.
 
     Live part: every matrix-core launch of `--profile-steps` extra steps is bracketed by a HIP event pair on the
-    stream it is launched on.  These steps are launched eagerly (an event inside a replayed graph cannot be timed
+    stream it is launched on (a 40 us spin kernel ahead of each pair keeps that stream busy while the host enqueues
+    pair and launch, so the pair does not span the host's launch gap).  These steps are launched eagerly (an event inside a replayed graph cannot be timed
     with this torch build) but with the step's own stream topology -- weight gradients and the text branch on helper
     streams beside the data-gradient chain -- so a kernel is stretched by its neighbours as it is in the timed replay.
     Which kernel is dominant is decided by total time per step, first in the committed rocprofv3 summary of the
@@ -145,7 +146,8 @@ def kernel_roofline(args, ts, model, fe, batches, use_graph, distributed):
            "unit": "TFLOP/s", "frac": round(ach / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
            "traffic_source": traffic_src, "algorithmic_flop_per_launch": round(fl / cnt),
            "launches": cnt, "avg_launch_us": round(ms * 1e3 / cnt, 2),
-           "measured": "HIP event pairs on the launch stream, eager steps with the step's helper streams on",
+           "measured": "HIP event pairs on the launch stream (each behind a 40 us spin kernel), eager steps with the "
+                       "step's helper streams on",
            "dominant_by": dominant_by}
     if kind in summary:
         avg_us = summary[kind][0]

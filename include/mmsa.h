@@ -336,6 +336,9 @@ MMSA_API int mmsa_scalar_axpy(float* dst, const float* a, const float* b, float 
 /* Diagnostic (no counterpart in the reference): buf[slot] <- the GPU's 100 MHz real-time counter when `stream` reaches
  * this point; see tools/step_stamps.py. */
 MMSA_API int mmsa_stamp(unsigned long long* buf, int slot, void* stream);
+/* Diagnostic (no counterpart in the reference): keeps `stream` busy for about `microseconds` (<= 10 000), so that what
+ * the host enqueues behind it is complete before the GPU gets there (bench.py's event pairs around single launches). */
+MMSA_API int mmsa_spin(int microseconds, void* stream);
 MMSA_API int mmsa_copy_multi(const void* const* srcs, void* const* dsts, const long* bytes, int n, void* stream);
 
 #ifdef __cplusplus

@@ -208,7 +208,26 @@ __global__ void stamp_kernel(unsigned long long* __restrict__ buf, int slot) {
   buf[slot] = __builtin_amdgcn_s_memrealtime();
 }
 
+// diagnostic: one thread waits until `ticks` ticks of the real-time counter have passed (bounded: gives up after
+// 2^22 polls, a few hundred milliseconds, whatever the counter does)
+__global__ void spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < (1 << 22); ++i) {
+    if (__builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+
 }  // namespace
+
+// Diagnostic: keeps `stream` busy for about `microseconds` (at most 10 000).  Enqueued ahead of an event pair around
+// a launch, it lets the host enqueue the pair and the launch before the GPU gets there, so that the pair times the
+// kernel and not the host's launch gap.
+MMSA_EXPORT int mmsa_spin(int microseconds, void* stream) {
+  MMSA_REQUIRE(microseconds > 0 && microseconds <= 10000);
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(1), 0, mmsa_stream(stream), (unsigned long long)microseconds * 100ull);
+  return mmsa_launch_status();
+}
 
 // Diagnostic: buf[slot] <- the GPU's real-time counter (ticks of 10 ns) when the stream reaches this point.  Placed
 // between the launches of a captured sequence it shows when each stream really gets there during an unprofiled

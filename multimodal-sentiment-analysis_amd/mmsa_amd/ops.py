@@ -27,11 +27,18 @@ TAPS1X1 = [(0, 0)]
 PROFILE = None
 
 
+# Microseconds the launch stream is kept busy ahead of each bracketed launch: the host then has the first event, the
+# launch and the second event enqueued before the GPU reaches them, and the pair times the kernel, not the launch gap.
+PROFILE_DELAY_US = 40
+
+
 def _prof_begin(kind: str, flops: float):
     if PROFILE is None:
         return None
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     PROFILE.setdefault(kind, []).append((s, e, flops))
+    if PROFILE_DELAY_US:
+        _lib.call("mmsa_spin", int(PROFILE_DELAY_US), _stream())
     s.record()
     return e
 
