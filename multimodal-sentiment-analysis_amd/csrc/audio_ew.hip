@@ -164,13 +164,30 @@ __global__ __launch_bounds__(256) void stem_bwd_stats_kernel(const float* __rest
   const float mean = coeff[c], istd = coeff[STEM_C + c], sc = coeff[2 * STEM_C + c], sh = coeff[3 * STEM_C + c];
   __syncthreads();
   float s1 = 0.f, s2 = 0.f;
-  for (int w2 = pl; w2 < W2; w2 += 8) {
+  // lane group pl takes a run of consecutive pooled columns and slides a 4x4 window along the staged rows
+  const int per = (W2 + 7) / 8;
+  const int w_first = pl * per, w_last = min(W2, w_first + per);
+  float win[4][4];
+  if (w_first < w_last) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      win[r][0] = sm[r * ldw + 2 * w_first];
+      win[r][1] = sm[r * ldw + 2 * w_first + 1];
+    }
+  }
+  for (int w2 = w_first; w2 < w_last; ++w2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      win[r][2] = sm[r * ldw + 2 * w2 + 2];
+      win[r][3] = sm[r * ldw + 2 * w2 + 3];
+    }
     float best = -INFINITY, bestconv = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const float v = stem_conv(sm + i * ldw, sm + (i + 1) * ldw, sm + (i + 2) * ldw, 2 * w2 + j, k, bs);
+        const float v = stem_conv_win(win[i][j], win[i][j + 1], win[i][j + 2], win[i + 1][j], win[i + 1][j + 1],
+                                      win[i + 1][j + 2], win[i + 2][j], win[i + 2][j + 1], win[i + 2][j + 2], k, bs);
         const float y = fmaxf(fmaf(v, sc, sh), 0.f);
         if (y > best) { best = y; bestconv = v; }
       }
@@ -178,6 +195,11 @@ __global__ __launch_bounds__(256) void stem_bwd_stats_kernel(const float* __rest
       const float d = dout[(((long)b * H2 + h2) * W2 + w2) * STEM_C + c];
       s1 += d;
       s2 = fmaf(d, (bestconv - mean) * istd, s2);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      win[r][0] = win[r][2];
+      win[r][1] = win[r][3];
     }
   }
   red[(pl * 2 + 0) * 32 + c] = s1;
@@ -217,7 +239,24 @@ __global__ __launch_bounds__(256) void stem_bwd_w_kernel(const float* __restrict
   for (int i = 0; i < 10; ++i) acc[i] = 0.f;
   // columns: pooled windows cover w < 2*W2; a trailing odd column still receives the dense BN terms
   const int ncol = (W + 1) / 2;
-  for (int w2 = pl; w2 < ncol; w2 += 8) {
+  // lane group pl takes a run of consecutive column pairs; the 4x4 window holds every input value the four
+  // convolution values and their nine weight-gradient products need
+  const int per = (ncol + 7) / 8;
+  const int w_first = pl * per, w_last = min(ncol, w_first + per);
+  float win[4][4];
+  if (w_first < w_last) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      win[r][0] = sm[r * ldw + 2 * w_first];
+      win[r][1] = sm[r * ldw + 2 * w_first + 1];
+    }
+  }
+  for (int w2 = w_first; w2 < w_last; ++w2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      win[r][2] = sm[r * ldw + 2 * w2 + 2];
+      win[r][3] = 2 * w2 + 3 < ldw ? sm[r * ldw + 2 * w2 + 3] : 0.f;   // past the staged row only for an odd width
+    }
     float conv[2][2];
     float best = -INFINITY;
     int bi = 0;
@@ -226,7 +265,10 @@ __global__ __launch_bounds__(256) void stem_bwd_w_kernel(const float* __restrict
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int w = 2 * w2 + j;
-        conv[i][j] = (w < W) ? stem_conv(sm + i * ldw, sm + (i + 1) * ldw, sm + (i + 2) * ldw, w, k, bs) : 0.f;
+        conv[i][j] = (w < W) ? stem_conv_win(win[i][j], win[i][j + 1], win[i][j + 2], win[i + 1][j], win[i + 1][j + 1],
+                                             win[i + 1][j + 2], win[i + 2][j], win[i + 2][j + 1], win[i + 2][j + 2], k,
+                                             bs)
+                             : 0.f;
         const float y = fmaxf(fmaf(conv[i][j], sc, sh), 0.f);
         if (y > best) { best = y; bi = i * 2 + j; }
       }
@@ -241,15 +283,20 @@ __global__ __launch_bounds__(256) void stem_bwd_w_kernel(const float* __restrict
           const float dz = (pooled && (i * 2 + j) == bi) ? d : 0.f;
           const float xh = (conv[i][j] - mean) * istd;
           const float dc = sc * (dz - m1 - xh * m2);
-          const float* r0 = sm + i * ldw + w;
-          acc[0] = fmaf(dc, r0[0], acc[0]); acc[1] = fmaf(dc, r0[1], acc[1]); acc[2] = fmaf(dc, r0[2], acc[2]);
-          acc[3] = fmaf(dc, r0[ldw], acc[3]); acc[4] = fmaf(dc, r0[ldw + 1], acc[4]);
-          acc[5] = fmaf(dc, r0[ldw + 2], acc[5]);
-          acc[6] = fmaf(dc, r0[2 * ldw], acc[6]); acc[7] = fmaf(dc, r0[2 * ldw + 1], acc[7]);
-          acc[8] = fmaf(dc, r0[2 * ldw + 2], acc[8]);
+          acc[0] = fmaf(dc, win[i][j], acc[0]); acc[1] = fmaf(dc, win[i][j + 1], acc[1]);
+          acc[2] = fmaf(dc, win[i][j + 2], acc[2]);
+          acc[3] = fmaf(dc, win[i + 1][j], acc[3]); acc[4] = fmaf(dc, win[i + 1][j + 1], acc[4]);
+          acc[5] = fmaf(dc, win[i + 1][j + 2], acc[5]);
+          acc[6] = fmaf(dc, win[i + 2][j], acc[6]); acc[7] = fmaf(dc, win[i + 2][j + 1], acc[7]);
+          acc[8] = fmaf(dc, win[i + 2][j + 2], acc[8]);
           acc[9] += dc;
         }
       }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      win[r][0] = win[r][2];
+      win[r][1] = win[r][3];
+    }
   }
 #pragma unroll
   for (int i = 0; i < 10; ++i) red[(pl * 32 + c) * 10 + i] = acc[i];
@@ -262,15 +309,16 @@ __global__ __launch_bounds__(256) void stem_bwd_w_kernel(const float* __restrict
   }
 }
 
-// sum partial[rows][320] (c*10+k) -> dW[32*9], dbias[32].  64 columns per block, 16 waves split the rows.
-__global__ __launch_bounds__(1024) void stem_bwd_w_finalize_kernel(const float* __restrict__ partial, int rows,
-                                                                   float* __restrict__ dW, float* __restrict__ db) {
-  __shared__ double red[16][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + lane;
+// sum partial[rows][320] (c*10+k) -> dW[32*9], dbias[32].  16 columns per workgroup of 256 threads: lane group
+// t >> 4 takes every sixteenth row (four loads in flight), the sixteen groups are added in fixed order.
+__global__ __launch_bounds__(256) void stem_bwd_w_finalize_kernel(const float* __restrict__ partial, int rows,
+                                                                  float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ double red[16][16];
+  const int cs = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int col = blockIdx.x * 16 + cs;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (col < 320) {
-    int r = w;
+    int r = rg;
     for (; r + 48 < rows; r += 64) {
       s0 += (double)partial[(long)r * 320 + col];
       s1 += (double)partial[(long)(r + 16) * 320 + col];
@@ -279,12 +327,12 @@ __global__ __launch_bounds__(1024) void stem_bwd_w_finalize_kernel(const float* 
     }
     for (; r < rows; r += 16) s0 += (double)partial[(long)r * 320 + col];
   }
-  red[w][lane] = (s0 + s1) + (s2 + s3);
+  red[rg][cs] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (w == 0 && col < 320) {
+  if (rg == 0 && col < 320) {
     double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    for (int k = 0; k < 16; ++k) t += red[k][cs];
     const int c = col / 10, k = col - c * 10;
     if (k < 9) dW[c * 9 + k] = (float)t; else db[c] = (float)t;
   }
@@ -497,13 +545,28 @@ __global__ void gate_affine_add_kernel(const f32x4* __restrict__ a, const float*
   }
 }
 
-__global__ void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int P, int C) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * C) return;
-  const int b = i / C, c = i - b * C;
-  float s = 0.f;
-  for (int p = 0; p < P; ++p) s += x[((long)b * P + p) * C + c];
-  out[i] = s / (float)P;
+// grid = (ceil(C / 64), B): the four waves of a workgroup take every fourth position of 64 channels (four loads in
+// flight per lane), and their sums are added in wave order.
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int P,
+                                                      int C) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    const float* xb = x + (long)b * P * C + c;
+    int p = w;
+    for (; p + 12 < P; p += 16) {
+      s0 += xb[(long)p * C];
+      s1 += xb[(long)(p + 4) * C];
+      s2 += xb[(long)(p + 8) * C];
+      s3 += xb[(long)(p + 12) * C];
+    }
+    for (; p < P; p += 4) s0 += xb[(long)p * C];
+  }
+  part[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && c < C) out[(long)b * C + c] = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) / (float)P;
 }
 
 __global__ void gap_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dx, int B, int P, int C) {
@@ -906,7 +969,7 @@ MMSA_EXPORT int mmsa_stem_bwd(const float* x, const float* w, const float* bias,
   const size_t sh2 = (4 * (W + 2) + 8 * 320) * sizeof(float);
   const float inv_n = training ? 1.0f / ((float)B * H * W) : 0.f;
   hipLaunchKernelGGL(stem_bwd_w_kernel, dim3(rows), dim3(256), sh2, s, x, w, bias, coeff, dout, s12, inv_n, p2, H, W);
-  hipLaunchKernelGGL(stem_bwd_w_finalize_kernel, dim3(5), dim3(1024), 0, s, p2, rows, dW, dbias);
+  hipLaunchKernelGGL(stem_bwd_w_finalize_kernel, dim3(20), dim3(256), 0, s, p2, rows, dW, dbias);
   return mmsa_launch_status();
 }
 
@@ -982,8 +1045,8 @@ MMSA_EXPORT int mmsa_gate_affine_add(const float* a, const float* coeff2, const 
 
 MMSA_EXPORT int mmsa_gap_fwd(const float* x, float* out, int B, int P, int C, void* stream) {
   MMSA_REQUIRE(x && out && B > 0 && P > 0 && C > 0);
-  hipLaunchKernelGGL(gap_fwd_kernel, dim3(mmsa_cdiv((long)B * C, 256)), dim3(256), 0, mmsa_stream(stream), x, out, B, P,
-                     C);
+  MMSA_REQUIRE(B <= 65535);
+  hipLaunchKernelGGL(gap_fwd_kernel, dim3(mmsa_cdiv(C, 64), B), dim3(256), 0, mmsa_stream(stream), x, out, B, P, C);
   return mmsa_launch_status();
 }
 
