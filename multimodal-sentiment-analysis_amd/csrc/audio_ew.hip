@@ -387,11 +387,16 @@ __device__ __forceinline__ void bn_finalize_body(const float* __restrict__ parti
     coeff[3 * C + c] = beta[c] - mean * sc;
   }
   if (bsum) {
+    // eight lanes per utterance: each takes every eighth tile, the eight sums meet through lane exchanges
     const int B = rows / tiles_per_img;
-    for (int b = threadIdx.x; b < B; b += 256) {
+    const int sub = threadIdx.x & 7;
+    for (int b = threadIdx.x >> 3; b < B; b += 32) {
       float t = 0.f;
-      for (int i = 0; i < tiles_per_img; ++i) t += ps[(long)b * tiles_per_img + i];
-      bsum[(long)b * C + c] = t;
+      for (int i = sub; i < tiles_per_img; i += 8) t += ps[(long)b * tiles_per_img + i];
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      if (sub == 0) bsum[(long)b * C + c] = t;
     }
   }
 }
@@ -720,10 +725,11 @@ __global__ __launch_bounds__(256) void rb_bwd_coeff_kernel(const float* __restri
                                                            float* __restrict__ dgamma2, float* __restrict__ dbeta2,
                                                            float* __restrict__ dgammas, float* __restrict__ dbetas,
                                                            float* __restrict__ tab, int training) {
-  // 64 channels per block (lane = channel: coalesced), the four waves split the utterances; fixed-order combine
-  __shared__ double red[4][4][64];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  // 16 channels per block (16 consecutive lanes = 16 consecutive channels), sixteen lane groups split the utterances
+  // (two each at batch 32, so every load of the kernel is in flight at once); fixed-order combine
+  __shared__ double red[4][16][16];
+  const int lc = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + lc;
   const bool cv = c < C;
   float mean2 = 0.f, istd2 = 0.f, sc2 = 0.f, means = 0.f, istds = 0.f, scs = 0.f;
   if (cv) {
@@ -732,7 +738,8 @@ __global__ __launch_bounds__(256) void rb_bwd_coeff_kernel(const float* __restri
   }
   double S1 = 0.0, S2 = 0.0, S1s = 0.0, S2s = 0.0;
   if (cv)
-    for (int b = w; b < B; b += 4) {
+#pragma unroll 2
+    for (int b = grp; b < B; b += 16) {
       const float a1 = A[((long)b * 3 + 0) * C + c], a2 = A[((long)b * 3 + 1) * C + c];
       const float a3 = A[((long)b * 3 + 2) * C + c];
       const float s = gate[(long)b * C + c], g = dg[(long)b * C + c];
@@ -741,13 +748,14 @@ __global__ __launch_bounds__(256) void rb_bwd_coeff_kernel(const float* __restri
       S1s += (double)a1;
       S2s += (double)((a3 - means * a1) * istds);
     }
-  red[0][w][lane] = S1; red[1][w][lane] = S2; red[2][w][lane] = S1s; red[3][w][lane] = S2s;
+  red[0][grp][lc] = S1; red[1][grp][lc] = S2; red[2][grp][lc] = S1s; red[3][grp][lc] = S2s;
   __syncthreads();
   if (!cv) return;
-  S1 = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
-  S2 = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
-  S1s = (red[2][0][lane] + red[2][1][lane]) + (red[2][2][lane] + red[2][3][lane]);
-  S2s = (red[3][0][lane] + red[3][1][lane]) + (red[3][2][lane] + red[3][3][lane]);
+  S1 = S2 = S1s = S2s = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    S1 += red[0][k][lc]; S2 += red[1][k][lc]; S1s += red[2][k][lc]; S2s += red[3][k][lc];
+  }
   const float n = (float)B * hw;
   // in eval mode BatchNorm is a fixed affine map: only the scale survives
   const float m1 = training ? (float)S1 / n : 0.f, m2 = training ? (float)S2 / n : 0.f;
@@ -755,7 +763,7 @@ __global__ __launch_bounds__(256) void rb_bwd_coeff_kernel(const float* __restri
   float* P = tab;
   float* R = tab + (long)B * C;
   float* Q = tab + 2L * B * C;
-  if (w == 0) {
+  if (grp == 0) {
     dgamma2[c] = (float)S2; dbeta2[c] = (float)S1;
     dgammas[c] = (float)S2s; dbetas[c] = (float)S1s;
     Q[c] = -sc2 * istd2 * m2;
@@ -763,7 +771,8 @@ __global__ __launch_bounds__(256) void rb_bwd_coeff_kernel(const float* __restri
     Q[2 * C + c] = -scs * istds * m2s;                       // Qs
     Q[3 * C + c] = -scs * m1s + scs * istds * m2s * means;   // Rs
   }
-  for (int b = w; b < B; b += 4) {
+#pragma unroll 2
+  for (int b = grp; b < B; b += 16) {
     const float s = gate[(long)b * C + c], g = dg[(long)b * C + c];
     P[(long)b * C + c] = sc2 * s;
     R[(long)b * C + c] = sc2 * (g / hw - m1) + sc2 * istd2 * m2 * mean2;
@@ -1096,7 +1105,7 @@ MMSA_EXPORT int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const f
                      c2, sc, coeff2, coeffs, gate, dz, partial, H, W, C, chunk, nchunks);
   hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), 0, s, partial, nchunks, coeff2, gate, hid, W1, W2, A, du, dhp,
                      dg, C, Ch);
-  hipLaunchKernelGGL(rb_bwd_coeff_kernel, dim3(mmsa_cdiv(C, 64)), dim3(256), 0, s, A, gate, dg, bsum, coeff2, coeffs, B,
+  hipLaunchKernelGGL(rb_bwd_coeff_kernel, dim3(mmsa_cdiv(C, 16)), dim3(256), 0, s, A, gate, dg, bsum, coeff2, coeffs, B,
                      C, (float)(H * W), dgamma2, dbeta2, dgammas, dbetas, tab, training);
   // the squeeze-excite weight gradients feed only the optimiser: with null dW1 / dW2 they are left to
   // mmsa_resblock_bwd_se_wgrad, which the caller may put on another stream
