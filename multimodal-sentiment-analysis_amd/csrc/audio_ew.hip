@@ -462,20 +462,36 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   }
   __syncthreads();
   const int lane = t & 63, w = t >> 6;
-  for (int j = w; j < Ch; j += 4) {
-    float a = 0.f;
-    for (int c = lane; c < C; c += 64) a = fmaf(W1[(long)j * C + c], g[c], a);
-    a = wave_sum(a);
-    if (lane == 0) {
-      a = fmaxf(a, 0.f);
-      hd[j] = a;
-      hid[(long)b * Ch + j] = a;
+  // wave w takes hidden units w, w + 4, w + 8, w + 12 together (their weight rows are requested at once), then the
+  // next sixteen; each unit's sum keeps its order
+  for (int j0 = w; j0 < Ch; j0 += 16) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = lane; c < C; c += 64) {
+      const float gc = g[c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + 4 * u < Ch) a[u] = fmaf(W1[(long)(j0 + 4 * u) * C + c], gc, a[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float v = fmaxf(wave_sum(a[u]), 0.f);
+      if (lane == 0 && j0 + 4 * u < Ch) {
+        hd[j0 + 4 * u] = v;
+        hid[(long)b * Ch + j0 + 4 * u] = v;
+      }
     }
   }
   __syncthreads();
   if (t < C) {
     float a = 0.f;
-    for (int j = 0; j < Ch; ++j) a = fmaf(W2[(long)t * Ch + j], hd[j], a);
+    const float* wr = W2 + (long)t * Ch;
+    int j = 0;
+    for (; j + 4 <= Ch && (Ch & 3) == 0; j += 4) {           // rows of W2 are 16-byte aligned when Ch % 4 == 0
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + j);
+      a = fmaf(w4[0], hd[j], a); a = fmaf(w4[1], hd[j + 1], a);
+      a = fmaf(w4[2], hd[j + 2], a); a = fmaf(w4[3], hd[j + 3], a);
+    }
+    for (; j < Ch; ++j) a = fmaf(wr[j], hd[j], a);
     gate[(long)b * C + t] = 1.0f / (1.0f + expf(-a));
   }
 }
@@ -697,20 +713,37 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ p
   }
   __syncthreads();
   const int lane = t & 63, w = t >> 6;
-  for (int j = w; j < Ch; j += 4) {
-    float a = 0.f;
-    for (int c = lane; c < C; c += 64) a = fmaf(W2[(long)c * Ch + j], sdu[c], a);
-    a = wave_sum(a);
-    if (lane == 0) {
-      a = hid[(long)b * Ch + j] > 0.f ? a : 0.f;
-      sdh[j] = a;
-      dhp[(long)b * Ch + j] = a;
+  // wave w takes hidden units w, w + 4, w + 8, w + 12 together (four loads in flight per channel), then the next
+  // sixteen; each unit's sum keeps its order
+  for (int j0 = w; j0 < Ch; j0 += 16) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = lane; c < C; c += 64) {
+      const float uc = sdu[c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (j0 + 4 * u < Ch) a[u] = fmaf(W2[(long)c * Ch + j0 + 4 * u], uc, a[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float v = wave_sum(a[u]);
+      const int j = j0 + 4 * u;
+      if (lane == 0 && j < Ch) {
+        v = hid[(long)b * Ch + j] > 0.f ? v : 0.f;
+        sdh[j] = v;
+        dhp[(long)b * Ch + j] = v;
+      }
     }
   }
   __syncthreads();
   if (t < C) {
     float a = 0.f;
-    for (int j = 0; j < Ch; ++j) a = fmaf(W1[(long)j * C + t], sdh[j], a);
+    int j = 0;
+    for (; j + 4 <= Ch; j += 4) {              // four weight loads in flight; the sum keeps its order
+      const float w0 = W1[(long)j * C + t], w1 = W1[(long)(j + 1) * C + t];
+      const float w2 = W1[(long)(j + 2) * C + t], w3 = W1[(long)(j + 3) * C + t];
+      a = fmaf(w0, sdh[j], a); a = fmaf(w1, sdh[j + 1], a); a = fmaf(w2, sdh[j + 2], a); a = fmaf(w3, sdh[j + 3], a);
+    }
+    for (; j < Ch; ++j) a = fmaf(W1[(long)j * C + t], sdh[j], a);
     dg[(long)b * C + t] = a;
   }
 }
