@@ -9,6 +9,9 @@ from __future__ import annotations
 
 from typing import List, Tuple
 
+import contextlib
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -66,13 +69,67 @@ class _HostStagedSum:
         return True
 
 
-def allreduce_buckets(flat: torch.Tensor, buckets, group=None, async_op: bool = False):
-    """Sum ``flat`` over ranks, one all-reduce per bucket (in place).  Returns the work handles when async."""
+class _DirectSum:
+    """Sum of a bucket over ranks as a direct reduce-scatter + all-gather: every rank owns 1/world of the bucket,
+    receives that slice from every peer in ONE all-to-all (on a fully connected xGMI node all peer links carry data at
+    once, where a ring uses one link per direction), adds the world slices in rank order, and the reduced slices are
+    all-gathered.  The rank-order sum makes the result identical on every rank and independent of the transport.
+    Runs on a stream of its own; ``wait()`` makes the caller's stream wait for it."""
+
+    _scratch = {}
+
+    def __init__(self, part: torch.Tensor, group):
+        world = dist.get_world_size(group)
+        n = part.numel()
+        if n % world:
+            raise ValueError("direct all-reduce: the bucket length must be a multiple of the world size")
+        key = (part.device, n, world)
+        buf = _DirectSum._scratch.get(key)
+        if buf is None:
+            buf = _DirectSum._scratch[key] = torch.empty((world, n // world), dtype=part.dtype, device=part.device)
+        self.stream = None
+        if part.is_cuda:
+            self.stream = _comm_stream(part.device)
+            self.stream.wait_stream(torch.cuda.current_stream())
+        with (torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()):
+            dist.all_to_all_single(buf.view(-1), part, group=group)         # row r: my slice as rank r holds it
+            mine = part.view(world, -1)[dist.get_rank(group)]
+            mine.copy_(buf[0])
+            for r in range(1, world):                                        # rank order, whatever arrived first
+                mine.add_(buf[r])
+            dist.all_gather_into_tensor(part, mine.clone(), group=group)
+
+    def wait(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        return True
+
+
+_COMM_STREAMS = {}
+
+
+def _comm_stream(device):
+    s = _COMM_STREAMS.get(device)
+    if s is None:
+        s = _COMM_STREAMS[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def allreduce_buckets(flat: torch.Tensor, buckets, group=None, async_op: bool = False, algo: str = None):
+    """Sum ``flat`` over ranks, one exchange per bucket (in place).  Returns the work handles when async.
+    ``algo`` (default: environment MMSA_ALLREDUCE, else "rccl"): "rccl" = the backend's all-reduce (RCCL picks ring /
+    tree / direct by topology); "direct" = :class:`_DirectSum`, an explicit reduce-scatter + all-gather built from one
+    all-to-all and one all-gather per bucket."""
+    algo = algo or os.environ.get("MMSA_ALLREDUCE", "rccl")
     staged = flat.is_cuda and dist.get_backend(group) == "gloo"
     handles = []
     for lo, hi in buckets:
         if staged:
             h = _HostStagedSum(flat[lo:hi], group)
+            if not async_op:
+                h.wait()
+        elif algo == "direct":
+            h = _DirectSum(flat[lo:hi], group)
             if not async_op:
                 h.wait()
         else:

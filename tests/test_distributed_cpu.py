@@ -49,6 +49,18 @@ def _worker(rank, world, port, ret):
         P, R = parallel.gather_predictions(probs, preds, n)
         ok = torch.equal(R, torch.arange(n)) and torch.equal(P[:, 0], torch.arange(n, dtype=torch.float32))
         tb = parallel.train_batches(50, 4, 7, rank, world)
+        # the explicit reduce-scatter + all-gather against the backend's all-reduce (rank-order sums: same bits)
+        direct = torch.cat([grads[k].flatten() for k in keys]) / world
+        direct = torch.cat([direct, torch.zeros((-direct.numel()) % (world * 4))])
+        db = parallel.make_buckets(direct.numel(), 4096 * world)
+        for h in parallel.allreduce_buckets(direct, db, async_op=True, algo="direct"):
+            h.wait()
+        direct_ok = torch.equal(direct[:flat.numel()], flat)
+        try:
+            parallel.allreduce_buckets(torch.zeros(world + 1), [(0, world + 1)], algo="direct")
+            direct_ok = False
+        except ValueError:
+            pass
         # row-sparse exchange of the embedding table's gradient against the dense all-reduce of the same table
         table = grads["text_model.embedding.weight"].clone()
         dense = table.clone()
@@ -68,7 +80,7 @@ def _worker(rank, world, port, ret):
             differs = False
         except RuntimeError:
             differs = True
-        ret[rank] = (err, (ok, sparse_ok, differs), [b.tolist() for b in tb])
+        ret[rank] = (err, (ok, sparse_ok, differs, direct_ok), [b.tolist() for b in tb])
     finally:
         dist.destroy_process_group()
 
