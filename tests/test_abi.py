@@ -230,3 +230,26 @@ def test_torch_custom_ops_are_registered_for_the_gpu_only():
         assert "mmsa::" + name in str(op.default._schema)
     with pytest.raises(NotImplementedError):
         torch.ops.mmsa.bn_relu_apply(torch.zeros(8, 4), torch.zeros(16), torch.zeros(8, 4), 8, 4)
+
+
+def test_bench_reads_the_committed_rocprof_summary():
+    """bench.py names its dominant kernel after the newest committed rocprofv3 summary: the file must parse, hold the
+    matrix kernels under the names the launch wrappers use, and the traffic table must cover the dominant one."""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench._canon('"void conv_igemm_kernel<64, 64, 2, 2, true, false, 5>"') == \
+        "conv_igemm_kernel<64,64,2,2,true,false,5>"
+    rows, src = bench.rocprof_summary()
+    assert src and src.startswith("profiles/r") and src.endswith("_kernel_stats.csv")
+    matrix = [k for k in rows if k.startswith(("conv_igemm_kernel<", "conv_wgrad2_kernel<"))]
+    assert len(matrix) >= 8
+    top = max(matrix, key=lambda k: rows[k][1])
+    avg_us, total_us, calls = rows[top]
+    assert calls > 0 and abs(avg_us * calls - total_us) < 0.01 * total_us
+    tag = src.split("/")[1].split("_")[0]
+    traffic = json.load(open(os.path.join(root, "profiles", tag + "_pmc_traffic.json")))
+    assert top in {bench._canon(k) for k in traffic}
