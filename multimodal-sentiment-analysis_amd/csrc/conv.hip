@@ -697,6 +697,8 @@ __global__ __launch_bounds__(NW * 64) void wgrad_reduce_pair_kernel(const float*
     wgrad_reduce_body<NW>(partial1, dW1, nslabs1, 1, Cin, Cout, 0, (long)blockIdx.x - blocks9);
 }
 
+constexpr size_t WGRAD_LDS_MAX = 150 * 1024;   // LDS a weight-gradient workgroup may ask for
+
 struct WgradPlan {
   int R, strips_per_img, nstrips, nsplit, nslabs;
   size_t shmem;
@@ -968,6 +970,7 @@ MMSA_EXPORT long mmsa_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, 
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 64 || (ntaps != 1 && ntaps != 9))
     return MMSA_ERR_ARG;
   const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, ntaps);
+  if (p.shmem > WGRAD_LDS_MAX) return MMSA_ERR_LIMIT;   // a one-row strip of this map does not fit in LDS
   if (nsplit_out) *nsplit_out = p.nslabs;
   return (long)p.nslabs * ntaps * Cin * Cout;
 }
@@ -985,7 +988,7 @@ MMSA_EXPORT int mmsa_conv_wgrad(const float* X, const float* dY, float* workspac
   ConvGeom g;
   if (fill_geom(g, B, H, W, Cin, Cout, ntaps, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
   const WgradPlan p = plan_wgrad(B, H, W, Cin, Cout, ntaps);
-  MMSA_REQUIRE(p.shmem <= 150 * 1024);
+  if (p.shmem > WGRAD_LDS_MAX) return MMSA_ERR_LIMIT;
   hipStream_t s = mmsa_stream(stream);
   dim3 grid((Cin / 32) * (Cout / 64), p.nsplit);
   if (ntaps == 9) {
@@ -1022,7 +1025,7 @@ MMSA_EXPORT int mmsa_conv_wgrad_pair(const float* X, const float* dY9, const flo
   if (fill_geom(g1, B, H, W, Cin, Cout, 1, &zero, &zero) != MMSA_OK) return MMSA_ERR_ARG;
   const WgradPlan p9 = plan_wgrad(B, H, W, Cin, Cout, 9), p1 = plan_wgrad(B, H, W, Cin, Cout, 1);
   const size_t shmem = p9.shmem > p1.shmem ? p9.shmem : p1.shmem;
-  MMSA_REQUIRE(shmem <= 150 * 1024);
+  if (shmem > WGRAD_LDS_MAX) return MMSA_ERR_LIMIT;
   hipStream_t s = mmsa_stream(stream);
   if (shmem > 48 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_pair_kernel),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)

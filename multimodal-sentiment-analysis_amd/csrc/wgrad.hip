@@ -74,7 +74,7 @@ Wg2Plan wg2_plan(int B, int H, int W, int Cin, int Cout, bool sc) {
     const long cost = (long)((H + R - 1) / R) * (R + 1);
     if (!best || cost <= best_cost) { best = R; best_cost = cost; }
   }
-  if (!best) return p;   // R = 0: the geometry does not fit (rows wider than about 290 positions)
+  if (!best) return p;   // R = 0: two one-row strips do not fit (rows wider than about 120 positions, 85 with shortcut)
   p.R = best;
   p.strips_per_img = (H + best - 1) / best;
   p.nstrips = B * p.strips_per_img;

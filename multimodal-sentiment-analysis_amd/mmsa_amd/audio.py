@@ -281,6 +281,9 @@ def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Works
         raise ValueError("audio input must be [B,1,H,W]")
     if H % 16 or W < 16:
         raise ValueError("spectrogram height must be a multiple of 16 and width at least 16")
+    if need_grad and not ops.conv_wgrad_supported(B, H // 2, W // 2, 32, 64):
+        raise ValueError(f"a spectrogram of {W} frames is too wide to train on: the weight-gradient kernels stage whole "
+                         "rows of the first block's map in LDS (at most 476 frames; inference has no such limit)")
     x = x.contiguous()
     st = SimpleNamespace(B=B, H=H, W=W, x=x, blocks=[])
     conv0, bn0 = m.conv1[0], m.conv1[1]

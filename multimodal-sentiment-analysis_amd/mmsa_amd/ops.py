@@ -331,6 +331,12 @@ def conv_wgrad_workspace(B, H, W, Cin, Cout, ntaps) -> int:
     return _lib.query("mmsa_conv_wgrad_workspace_floats", B, H, W, Cin, Cout, ntaps, None)
 
 
+def conv_wgrad_supported(B, H, W, Cin, Cout) -> bool:
+    """False when the map is too wide for any weight-gradient kernel (a one-row strip with its halo must fit in LDS:
+    about 238 columns for the 3x3 convolutions)."""
+    return _lib.load().mmsa_conv_wgrad_workspace_floats(B, H, W, Cin, Cout, 9, None) != -3
+
+
 def conv_wgrad(X, dY, dW, workspace, B, H, W, Cin, Cout, taps, w_valid=None, accumulate=False):
     if X.numel() != B * H * W * Cin or dY.numel() != B * H * W * Cout or dW.numel() != len(taps) * Cin * Cout:
         raise ValueError("conv_wgrad: operand sizes do not match the geometry")
@@ -363,8 +369,9 @@ def conv_wgrad_pair(X, dY9, dW9, dY1, dW1, ws9, ws1, B, H, W, Cin, Cout, taps=No
 
 
 def conv_wgrad_slab_count(B, H, W, Cin, Cout, with_shortcut: bool) -> int:
-    """Partial slabs one launch of :func:`conv_wgrad_slabs` writes for this geometry; 0 if a strip of the map does not
-    fit in LDS (rows wider than about 290 positions), in which case the first-generation kernels serve."""
+    """Partial slabs one launch of :func:`conv_wgrad_slabs` writes for this geometry; 0 if two one-row strips of the map
+    do not fit in LDS (rows wider than about 120 positions, 85 with the shortcut riding along), in which case the
+    first-generation kernels serve."""
     n = ctypes.c_int()
     rc = _lib.load().mmsa_conv_wgrad_slab_floats(B, H, W, Cin, Cout, int(with_shortcut),
                                                  ctypes.cast(ctypes.byref(n), ctypes.c_void_p))

@@ -108,6 +108,41 @@ def test_gradients_match_float64_oracle(modality, B):
     print(f"worst relative L2 gradient error vs float64 oracle: {worst:.2e}")
 
 
+def test_gradients_for_a_spectrogram_of_another_length():
+    """An 11 s utterance (64 x 460 frames) through the audio model: the first block's map (230 columns) is too wide for
+    a double-buffered strip of the second-generation weight-gradient kernel, so the first generation serves it (and the
+    second block, whose shortcut does not fit beside the 115-column strip); the third block (57 columns) uses the
+    second generation's general-width instantiation.  Gradients against the float64 oracle, as above.  Wider still
+    (680 frames) training refuses with a message, inference runs."""
+    from mmsa_amd import ops
+    assert ops.conv_wgrad_slab_count(2, 32, 230, 32, 64, True) == 0 and ops.conv_wgrad_supported(2, 32, 230, 32, 64)
+    assert ops.conv_wgrad_slab_count(2, 16, 115, 128, 128, False) > 0
+    assert ops.conv_wgrad_slab_count(2, 16, 115, 64, 128, True) == 0
+    assert ops.conv_wgrad_slab_count(2, 8, 57, 128, 256, True) > 0
+    m = seeded_model("audio", vocab=SMALL_VOCAB).to(DEV).train()
+    sd = cpu_state(m)
+    g = torch.Generator().manual_seed(5)
+    audio = torch.randn(2, 1, 64, 460, generator=g)
+    label = torch.tensor([0, 2])
+    out = m(audio=audio.to(DEV), labels=label.to(DEV))
+    out["loss"].backward()
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    o64, g64, _ = model_ref.forward_backward(sd64, "audio", audio.double(), None, label)
+    close(out["logits"], o64["logits"])
+    for k, p in m.named_parameters():
+        if is_noise_grad("audio", k):
+            continue
+        r = g64[k]
+        err = float(torch.linalg.vector_norm(p.grad.detach().cpu().double() - r) / (torch.linalg.vector_norm(r) + 1e-30))
+        assert err < 1e-3, f"{k}: relative L2 error {err:.3e}"
+    wide = torch.randn(2, 1, 64, 680, generator=g).to(DEV)
+    with pytest.raises(ValueError, match="too wide to train"):
+        m(audio=wide, labels=label.to(DEV))
+    with torch.no_grad():
+        ow = m.eval()(audio=wide)
+    close(ow["logits"], model_ref.forward(cpu_state(m), "audio", wide.cpu(), None, training=False)["logits"])
+
+
 def test_bn_buffers_after_three_train_forwards(golden):
     npz = golden["npz"]
     m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
