@@ -95,10 +95,11 @@ MMSA_API int mmsa_conv_pack_weights(const float* w, float* fwd, float* dgrad, in
  * {const float* w; float* fwd; float* dgrad; int Cout, Cin, ntaps, pad;} of mmsa_conv_pack_desc_bytes() bytes each */
 MMSA_API int mmsa_conv_pack_desc_bytes(void);
 MMSA_API int mmsa_conv_pack_weights_multi(const void* descs, int n, void* stream);
+/* LDS ring depth the forward / data-gradient launch picks for this geometry, number of problems per launch and K loop
+ * length (kchunks = taps x Cin / 32, one tap more with a second operand pair): the last template argument of the
+ * kernel name a profiler prints */
+MMSA_API int mmsa_conv_ring_buffers(int B, int H, int W, int Cout, int nproblems, int kchunks);
 /* tile height the forward kernel uses for this geometry; statistics rows = B * ceil(H*W / tile height) */
-/* LDS ring depth the forward / data-gradient launch picks for this geometry and number of problems per launch (the
- * last template argument of the kernel name a profiler prints) */
-MMSA_API int mmsa_conv_ring_buffers(int B, int H, int W, int Cout, int nproblems);
 MMSA_API int mmsa_conv_tile_rows(int B, int H, int W, int Cout);
 /* Y[B,H,W,Cout] (= or +=) sum_t X[b, h+dh[t], w+dw[t], :] . Wp[t][:, :]; reads outside the image are zero.
  * dh/dw are host arrays.  stats (optional): [2][Cout][B*tiles] per-tile column sums and sums of squares. */
@@ -120,11 +121,15 @@ MMSA_API int mmsa_conv_fwd_dual_split(const float* X, const float* Wp, const flo
 /* n (<= 4) convolutions of one input in one launch -- the text branch's filter widths (multimodal_model.py:186-188),
  * or a residual block's first 3x3 convolution together with its 1x1 shortcut (:48-49,64-68): problem i uses
  * Wp_host[i], entries tap0_host[i] .. tap0_host[i] + ntaps_host[i] - 1 of the offset table (tap0_host null: 0) and
- * writes Y_host[i]; stats_host (null, or n pointers) receives each problem's statistics as in mmsa_conv_fwd. */
+ * writes Y_host[i]; stats_host (null, or n pointers) receives each problem's statistics as in mmsa_conv_fwd.
+ * bnrelu_host (null, or n pointers, each null or a [4][Cout] BatchNorm coefficient table as mmsa_bn_finalize writes
+ * it): problem i stores max(scale * conv + shift, 0) -- eval-mode BatchNorm + ReLU (multimodal_model.py:64) folded
+ * into the convolution, for inference, where the table comes from the running statistics (stats_host must be null
+ * with it). */
 MMSA_API int mmsa_conv_fwd_multi(const float* X, const float* const* Wp_host, float* const* Y_host,
-                                 const int* ntaps_host, const int* tap0_host, float* const* stats_host, int n, int B,
-                                 int H, int W, int Cin, int Cout, int ntable, const int* dh_host, const int* dw_host,
-                                 void* stream);
+                                 const int* ntaps_host, const int* tap0_host, float* const* stats_host,
+                                 const float* const* bnrelu_host, int n, int B, int H, int W, int Cin, int Cout,
+                                 int ntable, const int* dh_host, const int* dw_host, void* stream);
 MMSA_API long mmsa_conv_wgrad_workspace_floats(int B, int H, int W, int Cin, int Cout, int ntaps, int* nsplit_host);
 /* dW[Cout][Cin][ntaps] (= or +=) sum_{b,h,w} X[b,h+dh,w+dw,cin] * dY[b,h,w,cout], in two launches on one stream:
  * mmsa_conv_wgrad writes partial slabs into workspace, mmsa_conv_wgrad_reduce sums them into dW in fixed order */

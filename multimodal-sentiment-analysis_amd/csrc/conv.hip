@@ -128,6 +128,8 @@ struct ConvMulti {
   const float* Wp[4];
   float* Y[4];
   float* stats[4];    // per-problem statistics (STATS instantiations)
+  const float* bnrelu[4];   // per-problem [4][Cout] BatchNorm table (rows 2, 3 = scale, shift) applied with a ReLU to
+                            // the result before it is stored, or null: inference, where the table is known beforehand
   // optional second operand pair appended to the K loop: Y += X2[b, p, :] . Wp2[:, :] (a 1x1 convolution of another
   // tensor with the same channel count, e.g. the shortcut's data gradient next to the 3x3 one)
   const float* X2;
@@ -142,15 +144,24 @@ __device__ unsigned long long* g_lab_stamps;
   do {                                                                                                 \
     if (threadIdx.x == 0 && g_lab_stamps) {                                                            \
       const long wg_ = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;           \
-      g_lab_stamps[wg_ * 8 + (i)] = __builtin_amdgcn_s_memtime();                                      \
-      g_lab_stamps[wg_ * 8 + 4 + (i)] = __builtin_amdgcn_s_memrealtime();                              \
+      g_lab_stamps[wg_ * 16 + (i)] = __builtin_amdgcn_s_memtime();                                     \
+      g_lab_stamps[wg_ * 16 + 4 + (i)] = __builtin_amdgcn_s_memrealtime();                             \
+    }                                                                                                  \
+  } while (0)
+// loader-side stamps (first lane of the first loader wave), slots 8 ..
+#define LAB_STAMP_L(i)                                                                                 \
+  do {                                                                                                 \
+    if (threadIdx.x == 256 && g_lab_stamps) {                                                          \
+      const long wg_ = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;           \
+      g_lab_stamps[wg_ * 16 + 8 + (i)] = __builtin_amdgcn_s_memtime();                                 \
     }                                                                                                  \
   } while (0)
 #else
 #define LAB_STAMP(i)
+#define LAB_STAMP_L(i)
 #endif
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STATS, bool ACCUM, int NB>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STATS, bool ACCUM, int NB, bool BNRELU = false>
 __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict__ X, const float* __restrict__ Wp0,
                                                          float* __restrict__ Y0, float* __restrict__ stats,
                                                          const ConvGeom g, int tiles_per_img, const ConvMulti multi) {
@@ -220,13 +231,18 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
     const bool ok = p < HW;
     const int h = p / g.W, w = p - h * g.W;
     aoff[j] = (p * g.Cin + 4 * (lslot ^ ((r >> 1) & 7))) * 4;
-    unsigned m = 0;
-    for (int tp = 0; tp < ntaps; ++tp) {
-      const int hh = h + g.dh[tap0 + tp], ww = w + g.dw[tap0 + tp];
-      if (ok && hh >= 0 && hh < g.H && ww >= 0 && ww < g.W) m |= 1u << tp;
+    // validity of every entry of the offset table, then the problem's range of it: with constant indices the table
+    // arrives in a few wide scalar loads ahead of the loop (indexed by tap0 + tp, every iteration waited for a
+    // scalar load of its own: 6 000 cycles per workgroup before the first request went out)
+    unsigned mall = 0;
+#pragma unroll
+    for (int ta = 0; ta < MAX_TAPS; ++ta) {
+      const int hh = h + g.dh[ta], ww = w + g.dw[ta];   // no short-circuit: a branch per tap would fence the loads
+      mall |= (unsigned)(((unsigned)hh < (unsigned)g.H) & ((unsigned)ww < (unsigned)g.W)) << ta;
     }
+    unsigned m = (mall >> tap0) & ((1u << ntaps) - 1u);
     if (ok) m |= 1u << ntaps;   // the second operand's centre tap
-    amask[j] = m;
+    amask[j] = ok ? m : 0u;
   }
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) {
@@ -234,6 +250,7 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
     boff[j] = ((n0 + r) * g.Cin + 4 * (lslot ^ ((r >> 1) & 7))) * 4;
   }
   const int nchunks = (ntaps + (dual ? 1 : 0)) * (g.Cin / KC);
+  LAB_STAMP_L(0);
 
   // load cursor (uniform): which (tap, channel offset) the next request fetches; it stops at the last chunk, so the
   // trailing requests of the pipeline re-read that chunk harmlessly instead of branching.  The tap's offset is read
@@ -347,9 +364,12 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
   // ck+2 has landed).  Both then join the barrier that publishes chunk ck+2 and retires the reads of chunk ck.
   Frag f0, f1;
   if (loader) {
+    LAB_STAMP_L(1);
 #pragma unroll
     for (int i = 0; i < NBUF - 1; ++i) request_next();
+    LAB_STAMP_L(2);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 3) * LD) : "memory");
+    LAB_STAMP_L(3);
     __builtin_amdgcn_s_barrier();
     for (int ck = 0; ck < nchunks; ++ck) {
       if (!(MMSA_LAB_ABLATE & 1)) request_next();
@@ -385,9 +405,21 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
   LAB_STAMP(2);
   // epilogue: D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   float* Yb = Y + (long)b * HW * g.Cout;
-  float csum[TN], csq[TN];
+  // BNRELU instantiations (multi-problem launches only): a problem with a coefficient table stores
+  // max(scale * conv + shift, 0), the expression of bn_relu_apply_kernel
+  const float* __restrict__ ep = BNRELU && many ? multi.bnrelu[blockIdx.z] : nullptr;   // uniform
+  float csum[TN], csq[TN], esc[TN], esh[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) csum[j] = csq[j] = 0.f;
+  for (int j = 0; j < TN; ++j) {
+    csum[j] = csq[j] = 0.f;
+    esc[j] = 1.f;
+    esh[j] = 0.f;
+    if (BNRELU && ep) {
+      const int col = n0 + wn * WTN + j * 32 + li;
+      esc[j] = ep[2 * g.Cout + col];
+      esh[j] = ep[3 * g.Cout + col];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -398,7 +430,8 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
         const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int p = p0 + row;
         if (p < HW && !loader) {
-          float v = acc[i][j][r];
+          const float raw = acc[i][j][r];
+          const float v = BNRELU && ep ? fmaxf(fmaf(raw, esc[j], esh[j]), 0.f) : raw;
           float* dst = Yb + (long)p * g.Cout + col;
           if (ACCUM) {
             // a hardware float add at the L2: equal to read-add-write for a single writer, and with two writers onto
@@ -408,8 +441,8 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
             *dst = v;
           }
           if (STATS) {
-            csum[j] += v;
-            csq[j] = fmaf(v, v, csq[j]);
+            csum[j] += raw;
+            csq[j] = fmaf(raw, raw, csq[j]);
           }
         }
       }
@@ -749,27 +782,30 @@ int fill_geom(ConvGeom& g, int B, int H, int W, int Cin, int Cout, int ntaps, co
   return MMSA_OK;
 }
 
-template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM, int NB>
+template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM, int NB, bool BNRELU = false>
 int launch_igemm_ring(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int tiles, dim3 grid,
                       const ConvMulti& multi, hipStream_t s) {
   constexpr size_t shmem = NB * (size_t)(BM + BN) * KC * sizeof(float);
   static bool attr_set = false;   // raising the dynamic-LDS limit is sticky per kernel; benign if raced
   if (shmem > 48 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM, NB>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM, NB, BNRELU>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
       return MMSA_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM, NB>), grid, dim3(512), shmem, s, X, Wp, Y,
-                     stats, g, tiles, multi);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM, NB, BNRELU>), grid, dim3(512), shmem, s, X, Wp,
+                     Y, stats, g, tiles, multi);
   return mmsa_launch_status();
 }
 
 // Ring depth per launch.  The 64 x 64 tile takes 16 KiB per buffer: five buffers (two workgroups per CU, deeper
 // prefetch) unless a ring of three (three workgroups per CU) saves a whole round of workgroups over the chip's 256
-// CUs -- the 2080-position maps, whose 1056 workgroups need three rounds of 512 but two of 768 (5-9 % faster there;
-// on the smaller maps, which fit one round either way, the shallower ring loses 3-8 %).
-int pick_ring(int BM, int BN, long blocks) {
+// CUs -- the 2080-position maps at batch 32, whose 1056 workgroups need three rounds of 512 but two of 768 (5-9 %
+// faster there; on the smaller maps, which fit one round either way, the shallower ring loses 3-8 %).  On grids of many
+// rounds (inference batches) the third workgroup pays only where the K loop is short (kchunks = 32-channel chunks per
+// tile <= 18: a workgroup's 15-20 k cycle start-up is then as long as its loop and a third resident workgroup hides
+// it: 80 vs 68, 91 vs 85 TFLOP/s at batch 256); with longer loops the deeper ring wins (98 vs 95, 105 vs 92).
+int pick_ring(int BM, int BN, long blocks, int kchunks) {
   const int nb = igemm_nbuf(BM, BN);
   if (BM == 64 && BN == 64 && nb > 3) {
     static int ring3 = -1;   // MMSA_IGEMM_RING3=0 keeps five buffers everywhere (A/B aid)
@@ -777,20 +813,29 @@ int pick_ring(int BM, int BN, long blocks) {
       const char* e = getenv("MMSA_IGEMM_RING3");
       ring3 = e ? atoi(e) : 1;
     }
-    if (ring3 && (blocks + 767) / 768 < (blocks + 511) / 512) return 3;
+    if (ring3 && (blocks + 767) / 768 < (blocks + 511) / 512 && (kchunks <= 18 || blocks <= 1536)) return 3;
+  }
+  if (BM == 128 && BN == 64 && nb > 3) {
+    static int ring128 = -1;   // MMSA_IGEMM_RING128=3: two 128-row workgroups per CU (A/B aid)
+    if (ring128 < 0) {
+      const char* e = getenv("MMSA_IGEMM_RING128");
+      ring128 = e ? atoi(e) : 5;
+    }
+    if (ring128 == 3) return 3;
   }
   return nb;
 }
 
-template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM>
+template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM, bool BNRELU = false>
 int launch_igemm_one(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int tiles, dim3 grid,
                      const ConvMulti& multi, hipStream_t s) {
   constexpr int NB = igemm_nbuf(BM, BN);
-  if constexpr (BM == 64 && BN == 64 && NB > 3) {
-    if (pick_ring(BM, BN, (long)grid.x * grid.y * grid.z) == 3)
-      return launch_igemm_ring<BM, BN, WM_, WN_, STATS, ACCUM, 3>(X, Wp, Y, stats, g, tiles, grid, multi, s);
+  if constexpr (BN == 64 && NB > 3) {
+    const int kchunks = (g.ntaps + (multi.X2 ? 1 : 0)) * (g.Cin / KC);
+    if (pick_ring(BM, BN, (long)grid.x * grid.y * grid.z, kchunks) == 3)
+      return launch_igemm_ring<BM, BN, WM_, WN_, STATS, ACCUM, 3, BNRELU>(X, Wp, Y, stats, g, tiles, grid, multi, s);
   }
-  return launch_igemm_ring<BM, BN, WM_, WN_, STATS, ACCUM, NB>(X, Wp, Y, stats, g, tiles, grid, multi, s);
+  return launch_igemm_ring<BM, BN, WM_, WN_, STATS, ACCUM, NB, BNRELU>(X, Wp, Y, stats, g, tiles, grid, multi, s);
 }
 
 template <int BM, int BN, int WM_, int WN_>
@@ -828,20 +873,21 @@ static int pick_bm(int B, int H, int W, int Cout) {
     forced = e ? atoi(e) : 0;
   }
   if (forced == 64 || forced == 128) return forced;
-  // 64-row tiles (four resident workgroups per CU, fine-grained tail) unless the grid is large enough that the
-  // tail no longer matters and the higher arithmetic intensity of 128-row tiles wins (measured at batch 32:
-  // 64 rows are 15-20 % faster on the 2080-position maps, 2x faster on the 128/512-position ones)
-  const long blocks128 = (long)B * mmsa_cdiv((long)H * W, 128) * (Cout / 64 > 0 ? Cout / 64 : 1);
-  return blocks128 >= 2048 ? 128 : 64;
+  // 64-row tiles always: at batch 32 they are 15-20 % faster on the 2080-position maps and 2x faster on the 128/512-
+  // position ones (fine-grained tail, two or three workgroups per CU); at batch 256, where the tail no longer matters,
+  // the 128-row tile with its one workgroup per CU (five buffers of 24 KiB) reaches 56-93 TFLOP/s where 64 rows reach
+  // 80-105, and with two per CU (three buffers) it only draws level (75-105).  MMSA_CONV_BM=128 selects it for A/B.
+  (void)B; (void)H; (void)W; (void)Cout;
+  return 64;
 }
 
 // LDS ring depth (last template argument of the kernel instantiation) that a launch of `nproblems` convolutions with
 // this geometry uses: part of the kernel's name in profiler output.
-MMSA_EXPORT int mmsa_conv_ring_buffers(int B, int H, int W, int Cout, int nproblems) {
-  MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && nproblems > 0);
+MMSA_EXPORT int mmsa_conv_ring_buffers(int B, int H, int W, int Cout, int nproblems, int kchunks) {
+  MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && nproblems > 0 && kchunks > 0);
   const int bm = Cout % 64 ? 128 : pick_bm(B, H, W, Cout), bn = Cout % 64 ? 32 : 64;
   const long blocks = (long)B * mmsa_cdiv((long)H * W, bm) * (Cout / bn) * nproblems;
-  return pick_ring(bm, bn, blocks);
+  return pick_ring(bm, bn, blocks, kchunks);
 }
 
 MMSA_EXPORT int mmsa_conv_tile_rows(int B, int H, int W, int Cout) {
@@ -929,15 +975,20 @@ MMSA_EXPORT int mmsa_conv_fwd_dual_split(const float* X, const float* Wp, const 
 // n (<= 4) convolutions of the same input X in one launch: problem i uses packed weights Wp[i] ([ntaps[i]][Cout][Cin]),
 // entries tap0[i] .. tap0[i] + ntaps[i] - 1 of the shared offset table (tap0 null: every problem starts at entry 0) and
 // writes Y[i] ([B,H,W,Cout]); stats (null, or n pointers) receives each problem's per-tile column sums / sums of
-// squares in the layout of mmsa_conv_fwd.  Wp / Y / ntaps / tap0 / stats are host arrays.  ntable = entries of dh / dw.
+// squares in the layout of mmsa_conv_fwd; bnrelu (null, or n pointers, each null or a [4][Cout] BatchNorm coefficient
+// table whose rows 2 and 3 hold scale and shift): problem i stores max(scale * conv + shift, 0) instead of the
+// convolution -- for inference, where the table does not depend on the convolution's own statistics (stats must be
+// null then).  Wp / Y / ntaps / tap0 / stats / bnrelu are host arrays.  ntable = entries of dh / dw.
 MMSA_EXPORT int mmsa_conv_fwd_multi(const float* X, const float* const* Wp, float* const* Y, const int* ntaps,
-                                    const int* tap0, float* const* stats, int n, int B, int H, int W, int Cin, int Cout,
-                                    int ntable, const int* dh, const int* dw, void* stream) {
+                                    const int* tap0, float* const* stats, const float* const* bnrelu, int n, int B,
+                                    int H, int W, int Cin, int Cout, int ntable, const int* dh, const int* dw,
+                                    void* stream) {
   MMSA_REQUIRE(X && Wp && Y && ntaps && dh && dw && n >= 1 && n <= 4);
   MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % KC == 0 && Cout % 64 == 0);
   MMSA_REQUIRE(ntable >= 1 && ntable <= MAX_TAPS);
   ConvMulti m{};
   m.n = n;
+  bool any_bnrelu = false;
   for (int i = 0; i < n; ++i) {
     const int t0 = tap0 ? tap0[i] : 0;
     MMSA_REQUIRE(ntaps[i] >= 1 && t0 >= 0 && t0 + ntaps[i] <= ntable && Wp[i] && Y[i]);
@@ -947,10 +998,18 @@ MMSA_EXPORT int mmsa_conv_fwd_multi(const float* X, const float* const* Wp, floa
     m.Wp[i] = Wp[i];
     m.Y[i] = Y[i];
     m.stats[i] = stats ? stats[i] : nullptr;
+    m.bnrelu[i] = bnrelu ? bnrelu[i] : nullptr;
+    any_bnrelu = any_bnrelu || m.bnrelu[i];
   }
+  MMSA_REQUIRE(!(any_bnrelu && stats));   // the folded form is for inference: no statistics wanted there
   ConvGeom g;
   if (fill_geom(g, B, H, W, Cin, Cout, ntable, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
   float* st0 = stats ? stats[0] : nullptr;
+  if (any_bnrelu) {
+    const int tiles = mmsa_cdiv(H * W, 64);
+    return launch_igemm_one<64, 64, 2, 2, false, false, true>(X, m.Wp[0], m.Y[0], nullptr, g, tiles,
+                                                              dim3(B * tiles, Cout / 64, n), m, mmsa_stream(stream));
+  }
   if (stats && pick_bm(B, H, W, Cout) == 128)
     return launch_igemm<128, 64, 2, 2>(X, m.Wp[0], m.Y[0], st0, g, 0, m, mmsa_stream(stream));
   return launch_igemm<64, 64, 2, 2>(X, m.Wp[0], m.Y[0], st0, g, 0, m, mmsa_stream(stream));

@@ -22,6 +22,8 @@ FORK_WGRAD = _os.environ.get("MMSA_FORK_WGRAD", "1") != "0"
 FORK_ANY = _os.environ.get("MMSA_FORK", "1") != "0"     # 0: the whole step on one stream (diagnostics)
 # 1: a block's first 3x3 convolution and its 1x1 shortcut share one launch (and one BatchNorm coefficient launch)
 FWD_PAIR = _os.environ.get("MMSA_FWD_PAIR", "1") != "0"
+# 1: inference folds bn1 + ReLU into the epilogue of a block's first convolution (0: separate pass, as in training)
+FOLD_EVAL_RELU = _os.environ.get("MMSA_FOLD_EVAL_RELU", "1") != "0"
 # Weight-gradient kernels: "slabs" (default) = the DMA-fed second generation (one 512-thread workgroup per CU writes a
 # partial slab; a block's slabs are summed by one launch behind the block's last weight-gradient kernel, or with
 # MMSA_WGRAD_REDUCE=end by one launch for all layers at the end of the backward pass); "old" = the first generation
@@ -133,14 +135,24 @@ def _conv_bn(ws, name, X, wf, bn, B, H, W, Cin, Cout, taps, training, want_bsum)
     return Y, coeff, bsum
 
 
-def _conv_pair_bn(ws, name, X, w1f, wsf, bn1, bns, B, H, W, Cin, Cout, training):
+def _conv_pair_bn(ws, name, X, w1f, wsf, bn1, bns, B, H, W, Cin, Cout, training, fold_relu=False):
     """conv1 (3x3) and the shortcut (1x1, the centre tap of the same offset table) of a residual block in one launch,
-    then both BatchNorm coefficient sets in one launch."""
-    Y1 = ws.buf(name + ".c1.y", (B, H, W, Cout))
+    then both BatchNorm coefficient sets in one launch.  fold_relu (inference only: the coefficients come from the
+    running statistics, so they exist before the convolution): the first result is stored as relu(bn1(conv1)) by the
+    convolution's own epilogue and returned in place of the raw convolution."""
     Ys = ws.buf(name + ".sc.y", (B, H, W, Cout))
     c1 = ws.buf(name + ".c1.coeff", 4 * Cout)
     cs = ws.buf(name + ".sc.coeff", 4 * Cout)
     rows, tiles = ops.conv_stats_rows(B, H, W, Cout)
+    if fold_relu:
+        assert not training
+        H1 = ws.buf(name + ".h1", (B, H, W, Cout))
+        ops.bn_finalize_pair([None, None], rows, tiles, B * H * W, [_bn_args(bn1), _bn_args(bns)], False, [c1, cs],
+                             Cout)
+        ops.conv_fwd_multi(X, [w1f, wsf], [H1, Ys], [9, 1], B, H, W, Cin, Cout, ops.TAPS3X3, tap0_list=[0, 4],
+                           bnrelu_list=[c1, None])
+        return H1, c1, Ys, cs
+    Y1 = ws.buf(name + ".c1.y", (B, H, W, Cout))
     st = [ws.buf(name + ".c1.stats", rows * 2 * Cout), ws.buf(name + ".sc.stats", rows * 2 * Cout)] if training else None
     ops.conv_fwd_multi(X, [w1f, wsf], [Y1, Ys], [9, 1], B, H, W, Cin, Cout, ops.TAPS3X3, tap0_list=[0, 4],
                        stats_list=st)
@@ -156,7 +168,12 @@ def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: 
     s.w2f, s.w2d = packs[name + ".c2"]
     s.wsf, s.wsd = packs[name + ".sc"]
     fsc = None
-    if FWD_PAIR:
+    fold = FWD_PAIR and FOLD_EVAL_RELU and not training and not need_grad
+    if fold:
+        s.c1 = None
+        s.h1, s.coeff1, s.sc, s.coeffs = _conv_pair_bn(ws, name, a_in, s.w1f, s.wsf, blk.bn1, blk.shortcut[1], B, H, W,
+                                                       Cin, Cout, training, fold_relu=True)
+    elif FWD_PAIR:
         s.c1, s.coeff1, s.sc, s.coeffs = _conv_pair_bn(ws, name, a_in, s.w1f, s.wsf, blk.bn1, blk.shortcut[1], B, H, W,
                                                        Cin, Cout, training)
     else:
@@ -166,8 +183,9 @@ def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: 
                                          ops.TAPS1X1, training, False)
         s.c1, s.coeff1, _ = _conv_bn(ws, name + ".c1", a_in, s.w1f, blk.bn1, B, H, W, Cin, Cout, ops.TAPS3X3,
                                      training, False)
-    s.h1 = ws.buf(name + ".h1", (B, H, W, Cout))
-    ops.bn_relu_apply(s.c1, s.coeff1, s.h1, B * H * W, Cout)
+    if not fold:
+        s.h1 = ws.buf(name + ".h1", (B, H, W, Cout))
+        ops.bn_relu_apply(s.c1, s.coeff1, s.h1, B * H * W, Cout)
     s.c2, s.coeff2, s.bsum2 = _conv_bn(ws, name + ".c2", s.h1, s.w2f, blk.bn2, B, H, W, Cout, Cout, ops.TAPS3X3,
                                        training, True)
     W1, W2 = blk.se.fc[0].weight, blk.se.fc[2].weight

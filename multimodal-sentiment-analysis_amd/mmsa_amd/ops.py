@@ -43,12 +43,14 @@ def _prof_begin(kind: str, flops: float):
     return e
 
 
-def _igemm_name(bm, bn, stats, accum, geom, nproblems=1) -> str:
-    """Name of the kernel instantiation mmsa_conv_fwd launches for this tile (as rocprofv3 prints it, without spaces)."""
+def _igemm_name(bm, bn, stats, accum, geom, kchunks, nproblems=1, bnrelu=False) -> str:
+    """Name of the kernel instantiation mmsa_conv_fwd launches for this tile (as rocprofv3 prints it, without spaces);
+    kchunks = 32-channel chunks in a tile's K loop."""
     wm, wn = (4, 1) if bn == 32 else (2, 2)
-    ring = _lib.query("mmsa_conv_ring_buffers", *geom, nproblems)
-    return "conv_igemm_kernel<%d,%d,%d,%d,%s,%s,%d>" % (bm, bn, wm, wn, "true" if stats else "false",
-                                                         "true" if accum else "false", ring)
+    ring = _lib.query("mmsa_conv_ring_buffers", *geom, nproblems, kchunks)
+    return "conv_igemm_kernel<%d,%d,%d,%d,%s,%s,%d,%s>" % (bm, bn, wm, wn, "true" if stats else "false",
+                                                            "true" if accum else "false", ring,
+                                                            "true" if bnrelu else "false")
 
 
 def _stream() -> int:
@@ -253,7 +255,7 @@ def conv_fwd(X, Wp, Y, stats, B, H, W, Cin, Cout, taps, negate=False, accumulate
     ev = None
     if PROFILE is not None:
         bm, bn = (128, 32) if Cout % 64 else (conv_tile_rows(B, H, W, Cout), 64)
-        kind = _igemm_name(bm, bn, stats is not None, accumulate, (B, H, W, Cout))
+        kind = _igemm_name(bm, bn, stats is not None, accumulate, (B, H, W, Cout), len(taps) * Cin // 32)
         ev = _prof_begin(kind, 2.0 * B * H * W * Cin * Cout * len(taps))
     _lib.call("mmsa_conv_fwd", _chk(X), _chk(Wp), _chk(Y), _opt(stats), B, H, W, Cin, Cout, len(taps),
               _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), int(accumulate), _stream())
@@ -270,7 +272,7 @@ def conv_fwd_dual(X, Wp, X2, Wp2, Y, B, H, W, Cin, Cout, taps, negate=False):
     ev = None
     if PROFILE is not None:
         bm, bn = (128, 32) if Cout % 64 else (conv_tile_rows(B, H, W, Cout), 64)
-        ev = _prof_begin(_igemm_name(bm, bn, False, False, (B, H, W, Cout)),
+        ev = _prof_begin(_igemm_name(bm, bn, False, False, (B, H, W, Cout), (len(taps) + 1) * Cin // 32),
                          2.0 * B * H * W * Cin * Cout * (len(taps) + 1))
     _lib.call("mmsa_conv_fwd_dual", _chk(X), _chk(Wp), _chk(X2), _chk(Wp2), _chk(Y), B, H, W, Cin, Cout, len(taps),
               _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), _stream())
@@ -291,8 +293,8 @@ def conv_fwd_dual_split(X, Wp, X2, Wp2, Y, B, H, W, Cin, Cout, taps, negate=Fals
     sgn = -1 if negate else 1
     ev = None
     if PROFILE is not None:
-        ring = _lib.query("mmsa_conv_ring_buffers", B, H, W, Cout, 2)
-        ev = _prof_begin("conv_igemm_kernel<64,64,2,2,false,true,%d>" % ring,
+        ring = _lib.query("mmsa_conv_ring_buffers", B, H, W, Cout, 2, (len(taps) + 1) * Cin // 32)
+        ev = _prof_begin("conv_igemm_kernel<64,64,2,2,false,true,%d,false>" % ring,
                          2.0 * B * H * W * Cin * Cout * (len(taps) + 1))
     _lib.call("mmsa_conv_fwd_dual_split", _chk(X), _chk(Wp), _chk(X2), _chk(Wp2), _chk(Y), B, H, W, Cin, Cout,
               len(taps), _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), _stream())
@@ -300,9 +302,12 @@ def conv_fwd_dual_split(X, Wp, X2, Wp2, Y, B, H, W, Cin, Cout, taps, negate=Fals
         ev.record()
 
 
-def conv_fwd_multi(X, Wps, Ys, ntaps_list, B, H, W, Cin, Cout, taps, tap0_list=None, stats_list=None):
+def conv_fwd_multi(X, Wps, Ys, ntaps_list, B, H, W, Cin, Cout, taps, tap0_list=None, stats_list=None,
+                   bnrelu_list=None):
     """Several convolutions of X in one launch; problem i uses offsets tap0_list[i] .. + ntaps_list[i] of ``taps``
-    (from 0 when tap0_list is None) and, with stats_list, writes its per-tile statistics like :func:`conv_fwd`."""
+    (from 0 when tap0_list is None) and, with stats_list, writes its per-tile statistics like :func:`conv_fwd`.
+    bnrelu_list: per problem None or a [4][Cout] BatchNorm coefficient table; that problem then stores
+    relu(scale * conv + shift) (inference: the table does not depend on the convolution)."""
     n = len(Wps)
     if X.numel() != B * H * W * Cin or len(Ys) != n or len(ntaps_list) != n or n > 4:
         raise ValueError("conv_fwd_multi: bad arguments")
@@ -311,6 +316,9 @@ def conv_fwd_multi(X, Wps, Ys, ntaps_list, B, H, W, Cin, Cout, taps, tap0_list=N
         if wp.numel() != nt * Cin * Cout or y.numel() != B * H * W * Cout or t0 < 0 or t0 + nt > len(taps):
             raise ValueError("conv_fwd_multi: operand sizes do not match the geometry")
     bm = 64
+    if bnrelu_list is not None and (len(bnrelu_list) != n or any(c is not None and c.numel() != 4 * Cout
+                                                                 for c in bnrelu_list)):
+        raise ValueError("conv_fwd_multi: BatchNorm tables have the wrong size")
     if stats_list is not None:
         rows, _ = conv_stats_rows(B, H, W, Cout)
         bm = _lib.query("mmsa_conv_tile_rows", B, H, W, Cout)
@@ -318,11 +326,12 @@ def conv_fwd_multi(X, Wps, Ys, ntaps_list, B, H, W, Cin, Cout, taps, tap0_list=N
             raise ValueError("conv_fwd_multi: statistics buffers have the wrong size")
     ev = None
     if PROFILE is not None:
-        ev = _prof_begin(_igemm_name(bm, 64, stats_list is not None, False, (B, H, W, Cout), n),
+        ev = _prof_begin(_igemm_name(bm, 64, stats_list is not None, False, (B, H, W, Cout), len(taps) * Cin // 32, n,
+                                     bnrelu_list is not None and any(c is not None for c in bnrelu_list)),
                          2.0 * B * H * W * Cin * Cout * sum(ntaps_list))
     _lib.call("mmsa_conv_fwd_multi", _chk(X), _parr([_chk(w) for w in Wps]), _parr([_chk(y) for y in Ys]),
               _iarr(ntaps_list), _iarr(tap0_list), None if stats_list is None else _parr([_chk(t) for t in stats_list]),
-              n, B, H, W, Cin, Cout, len(taps), _iarr([t[0] for t in taps]), _iarr([t[1] for t in taps]), _stream())
+              None if bnrelu_list is None else _parr([_opt(c) for c in bnrelu_list]), n, B, H, W, Cin, Cout, len(taps), _iarr([t[0] for t in taps]), _iarr([t[1] for t in taps]), _stream())
     if ev is not None:
         ev.record()
 

@@ -156,6 +156,20 @@ def test_bn_buffers_after_three_train_forwards(golden):
             np.testing.assert_allclose(v.cpu().numpy(), npz[f"both.bn3.{k}"], rtol=1e-4, atol=1e-5)
 
 
+def test_inference_with_folded_batchnorm_equals_separate_pass(monkeypatch):
+    """Eval forward: bn1 + ReLU folded into each block's first convolution (the default) against the separate
+    element-wise pass the training forward uses -- identical logits, bit for bit."""
+    from mmsa_amd import audio as audio_mod
+    m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).eval()
+    b = batch_tensors(3, 37, vocab=SMALL_VOCAB, device=DEV)
+    outs = []
+    for fold in (True, False):
+        monkeypatch.setattr(audio_mod, "FOLD_EVAL_RELU", fold)
+        with torch.no_grad():
+            outs.append(m(**model_inputs("both", b))["logits"].clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_inference_batch_1024_chunked_equals_oracle_sample():
     """Config 5 shape: eval-mode batch 1024 goes through in chunks; spot-check 16 rows against the oracle and
     require chunking to be invisible (same rows evaluated alone give the same logits bit for bit)."""

@@ -252,6 +252,48 @@ def test_conv3x3_forward_and_stats(B, H, W, Cin, Cout):
     np.testing.assert_allclose(per_img.numpy(), refn.sum((1, 2)).numpy(), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 32, 65, 32, 64), (2, 16, 31, 64, 128), (40, 8, 16, 128, 256)])
+def test_paired_convolution_with_folded_batchnorm_relu(B, H, W, Cin, Cout):
+    """A block's 3x3 convolution and 1x1 shortcut in one launch, the first stored as relu(scale * conv + shift) by the
+    convolution's epilogue (inference): bit-identical to the plain launch followed by the BatchNorm + ReLU pass, the
+    second result untouched; both against float64 convolutions.  Statistics cannot be asked for together with it."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5 * B + Cin)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w3 = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cout)) ** 0.5
+    w1 = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1
+    coeff = torch.randn(4, Cout, generator=g).to(DEV)
+    xd = nhwc(x).to(DEV)
+    wf3, wf1 = torch.empty(w3.numel(), device=DEV), torch.empty(w1.numel(), device=DEV)
+    ops.pack_weights(w3.to(DEV), wf3, None)
+    ops.pack_weights(w1.to(DEV), wf1, None)
+    rows, _ = ops.conv_stats_rows(B, H, W, Cout)
+
+    def run(fold, with_stats):
+        y3 = torch.full((B, H, W, Cout), float("nan"), device=DEV)
+        y1 = torch.full((B, H, W, Cout), float("nan"), device=DEV)
+        st = [torch.zeros(2, Cout, rows, device=DEV) for _ in range(2)] if with_stats else None
+        ops.conv_fwd_multi(xd, [wf3, wf1], [y3, y1], [9, 1], B, H, W, Cin, Cout, ops.TAPS3X3, tap0_list=[0, 4],
+                           stats_list=st, bnrelu_list=[coeff.flatten(), None] if fold else None)
+        return y3, y1, st
+
+    raw3, raw1, _ = run(False, False)
+    two_pass = torch.empty_like(raw3)
+    ops.bn_relu_apply(raw3, coeff.flatten(), two_pass, B * H * W, Cout)
+    f3, f1, _ = run(True, False)
+    assert torch.equal(f3, two_pass)
+    assert torch.equal(f1, raw1)
+    with pytest.raises(Exception):
+        run(True, True)
+    ref3 = F.conv2d(x.double(), w3.double(), None, 1, 1)
+    ref = torch.relu(ref3 * coeff[2].cpu().double().view(1, -1, 1, 1) + coeff[3].cpu().double().view(1, -1, 1, 1))
+    check(nchw(f3.cpu()), ref, 2e-5)
+    check(nchw(f1.cpu()), F.conv2d(x.double(), w1.double()), 2e-6)
+    with pytest.raises(ValueError):
+        ops.conv_fwd_multi(xd, [wf3, wf1], [f3, f1], [9, 1], B, H, W, Cin, Cout, ops.TAPS3X3, tap0_list=[0, 4],
+                           bnrelu_list=[coeff.flatten()[:Cout], None])
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 32, 65, 32, 64), (2, 16, 32, 64, 128), (2, 8, 16, 128, 256)])
 def test_conv1x1_and_dgrad(B, H, W, Cin, Cout):
     ops = _ops()

@@ -44,8 +44,8 @@ int main(int argc, char** argv) {
   const long nwg = (long)B * tiles * (Cout / 64 > 0 ? Cout / 64 : 1) * 2;   // upper bound
   unsigned long long* stamps = nullptr;
 #ifdef MMSA_LAB_STAMPS
-  CK(hipMalloc(&stamps, nwg * 8 * sizeof(unsigned long long)));
-  CK(hipMemset(stamps, 0, nwg * 8 * sizeof(unsigned long long)));
+  CK(hipMalloc(&stamps, nwg * 16 * sizeof(unsigned long long)));
+  CK(hipMemset(stamps, 0, nwg * 16 * sizeof(unsigned long long)));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_lab_stamps), &stamps, sizeof(stamps)));
 #endif
   hipStream_t st;
@@ -67,16 +67,20 @@ int main(int argc, char** argv) {
   printf("B=%d H=%d W=%d Cin=%d Cout=%d taps=%d tile=%d: %.1f us  %.1f TFLOP/s\n", B, H, W, Cin, Cout, nt, bm, us,
          fl / us / 1e6);
 #ifdef MMSA_LAB_STAMPS
-  std::vector<unsigned long long> h(nwg * 8);
-  CK(hipMemcpy(h.data(), stamps, nwg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  std::vector<double> pro, loop, epi, tot, clk;
+  std::vector<unsigned long long> h(nwg * 16);
+  CK(hipMemcpy(h.data(), stamps, nwg * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  std::vector<double> pro, loop, epi, tot, clk, l_plan, l_acc, l_issue, l_wait;
   unsigned long long r0 = ~0ull, r1 = 0;
   std::vector<unsigned long long> starts, ends;
   for (long i = 0; i < nwg; ++i) {
-    const unsigned long long* p = &h[i * 8];
+    const unsigned long long* p = &h[i * 16];
     if (!p[3]) continue;
     pro.push_back((double)(p[1] - p[0])); loop.push_back((double)(p[2] - p[1])); epi.push_back((double)(p[3] - p[2]));
     tot.push_back((double)(p[3] - p[0]));
+    if (p[11]) {
+      l_plan.push_back((double)(p[8] - p[0])); l_acc.push_back((double)(p[9] - p[8]));
+      l_issue.push_back((double)(p[10] - p[9])); l_wait.push_back((double)(p[11] - p[10]));
+    }
     const double rt = (double)(p[7] - p[4]);       // 100 MHz ticks
     if (rt > 0) clk.push_back((double)(p[3] - p[0]) / rt * 100.0);
     r0 = std::min(r0, p[4]); r1 = std::max(r1, p[7]);
@@ -86,6 +90,8 @@ int main(int argc, char** argv) {
   auto mx = [](std::vector<double> v) { return v.empty() ? 0.0 : *std::max_element(v.begin(), v.end()); };
   printf("workgroups %zu: cycles median prologue %.0f, loop %.0f, epilogue %.0f, total %.0f (max %.0f); clock %.0f MHz\n",
          tot.size(), med(pro), med(loop), med(epi), med(tot), mx(tot), med(clk));
+  printf("loader wave: cycles median from workgroup start to plan done %.0f, to first request %.0f, issuing the prologue's requests %.0f, waiting for them %.0f\n",
+         med(l_plan), med(l_acc), med(l_issue), med(l_wait));
   std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
   const size_t n = starts.size();
   if (n) {
