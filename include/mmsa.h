@@ -99,6 +99,11 @@ MMSA_API int mmsa_conv_pack_weights_multi(const void* descs, int n, void* stream
  * length (kchunks = taps x Cin / 32, one tap more with a second operand pair): the last template argument of the
  * kernel name a profiler prints */
 MMSA_API int mmsa_conv_ring_buffers(int B, int H, int W, int Cout, int nproblems, int kchunks);
+/* 1 when the launchers below hand this geometry and offset table to the kernel that stages an input strip once per
+ * row of three taps (conv_igemm3_kernel: the 3x3 / pad 1 convolutions of multimodal_model.py:48-59 and their data
+ * gradients), 0 when the general kernel runs (conv_igemm_kernel: any offset table, e.g. the text Conv1d) */
+MMSA_API int mmsa_conv_shares_tap_rows(int B, int H, int W, int Cout, int ntaps, const int* dh_host,
+                                       const int* dw_host);
 /* tile height the forward kernel uses for this geometry; statistics rows = B * ceil(H*W / tile height) */
 MMSA_API int mmsa_conv_tile_rows(int B, int H, int W, int Cout);
 /* Y[B,H,W,Cout] (= or +=) sum_t X[b, h+dh[t], w+dw[t], :] . Wp[t][:, :]; reads outside the image are zero.
@@ -110,8 +115,9 @@ MMSA_API int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* sta
 MMSA_API int mmsa_conv_fwd_dual(const float* X, const float* Wp, const float* X2, const float* Wp2, float* Y, int B,
                                 int H, int W, int Cin, int Cout, int ntaps, const int* dh_host, const int* dw_host,
                                 void* stream);
-/* mmsa_conv_fwd_dual with the K range split over two workgroups per output tile (taps 0..4 | taps 5..8 plus the second
- * pair), for maps with at most one tile per CU of the chip (mmsa_conv_fwd_dual_prefers_split: 1 / 0).
+/* mmsa_conv_fwd_dual with the K range split over two workgroups per output tile (lower | upper half of the channels,
+ * every tap and the second pair in both; the general kernel splits taps 0..4 | taps 5..8 plus the second pair), for
+ * maps with at most one tile per CU of the chip (mmsa_conv_fwd_dual_prefers_split: 1 / 0).
  * Y MUST BE ZERO on entry: both halves add their part with hardware float atomics -- two addends per element, so the
  * result does not depend on their order.  3x3 offsets only, Cout a multiple of 64. */
 MMSA_API int mmsa_conv_fwd_dual_prefers_split(int B, int H, int W, int Cout);

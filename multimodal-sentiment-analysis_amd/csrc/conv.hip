@@ -473,6 +473,8 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
   LAB_STAMP(3);
 }
 
+#include "conv_rows3.h"
+
 // ------------------------------------------------------------------------------------------------
 // Weight gradient.  grid = (cin tiles of 32 x cout groups of 64, nsplit).  A workgroup walks over strips of R
 // image rows (strip = blockIdx.y, += gridDim.y); per strip it stages the X rows r0-1 .. r0+R with a zero halo
@@ -881,6 +883,21 @@ static int pick_bm(int B, int H, int W, int Cout) {
   return 64;
 }
 
+// Whether the launchers below hand this geometry / offset table to the strip-sharing kernel (conv_rows3.h).
+static bool uses_rows3(int B, int H, int W, int Cout, int ntaps, const int* dh, const int* dw) {
+  const int mode = rows3_mode();
+  if (!mode || !rows3_pattern(ntaps, dh, dw)) return false;
+  if (Cout % 64 == 0 && (mode < 2 || pick_bm(B, H, W, Cout) != 64)) return false;
+  // a strip has BM + 8 rows: BM + 2 positions plus one gap row per image-row end it spans (1 + (BM-1)/W at most)
+  const int bm = Cout % 64 ? 128 : 64;
+  return (bm - 1) / W <= 5;
+}
+
+MMSA_EXPORT int mmsa_conv_shares_tap_rows(int B, int H, int W, int Cout, int ntaps, const int* dh, const int* dw) {
+  MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && Cout > 0 && ntaps >= 1 && ntaps <= MAX_TAPS && dh && dw);
+  return uses_rows3(B, H, W, Cout, ntaps, dh, dw) ? 1 : 0;
+}
+
 // LDS ring depth (last template argument of the kernel instantiation) that a launch of `nproblems` convolutions with
 // this geometry uses: part of the kernel's name in profiler output.
 MMSA_EXPORT int mmsa_conv_ring_buffers(int B, int H, int W, int Cout, int nproblems, int kchunks) {
@@ -906,6 +923,15 @@ MMSA_EXPORT int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* 
   ConvGeom g;
   if (fill_geom(g, B, H, W, Cin, Cout, ntaps, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
   hipStream_t s = mmsa_stream(stream);
+  if (uses_rows3(B, H, W, Cout, ntaps, dh, dw)) {
+    if (Cout % 64 != 0 && stats) return MMSA_ERR_ARG;
+    Conv3Args a{};
+    a.n = 1;
+    a.ntaps[0] = 9; a.chunk0[0] = 0; a.chunk1[0] = Cin / KC;
+    a.Wp[0] = Wp; a.Y[0] = Y; a.stats[0] = stats;
+    a.second_z = -1;
+    return launch_igemm3(X, g, a, accumulate != 0, s);
+  }
   if (Cout % 64 != 0) {
     // 32-wide output (data gradient into a 32-channel tensor): 128 x 32 tiles, 4 x 1 waves
     if (stats) return MMSA_ERR_ARG;
@@ -928,6 +954,14 @@ MMSA_EXPORT int mmsa_conv_fwd_dual(const float* X, const float* Wp, const float*
   ConvGeom g;
   if (fill_geom(g, B, H, W, Cin, Cout, ntaps, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
   hipStream_t s = mmsa_stream(stream);
+  if (uses_rows3(B, H, W, Cout, ntaps, dh, dw)) {
+    Conv3Args a{};
+    a.n = 1;
+    a.ntaps[0] = 9; a.chunk0[0] = 0; a.chunk1[0] = Cin / KC;
+    a.Wp[0] = Wp; a.Y[0] = Y;
+    a.X2 = X2; a.Wp2 = Wp2; a.second_z = -1;
+    return launch_igemm3(X, g, a, false, s);
+  }
   ConvMulti m{};
   m.X2 = X2;
   m.Wp2 = Wp2;
@@ -961,6 +995,19 @@ MMSA_EXPORT int mmsa_conv_fwd_dual_split(const float* X, const float* Wp, const 
   MMSA_REQUIRE(Cin % KC == 0 && Cout % 64 == 0);
   ConvGeom g;
   if (fill_geom(g, B, H, W, Cin, Cout, ntaps, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
+  if (Cin / KC >= 2 && uses_rows3(B, H, W, Cout, ntaps, dh, dw)) {
+    // the two workgroups of a tile take the lower and the upper half of the channel chunks (all nine taps and the
+    // second pair each), so both walk whole rows of taps
+    Conv3Args a{};
+    a.n = 2;
+    const int half = (Cin / KC + 1) / 2;
+    for (int i = 0; i < 2; ++i) {
+      a.ntaps[i] = 9; a.chunk0[i] = i ? half : 0; a.chunk1[i] = i ? Cin / KC : half;
+      a.Wp[i] = Wp; a.Y[i] = Y_zeroed;
+    }
+    a.X2 = X2; a.Wp2 = Wp2; a.second_z = -1;
+    return launch_igemm3(X, g, a, true, mmsa_stream(stream));
+  }
   ConvMulti m{};
   m.n = 2;
   m.ntaps[0] = 5; m.tap0[0] = 0; m.Wp[0] = Wp;
@@ -1004,6 +1051,25 @@ MMSA_EXPORT int mmsa_conv_fwd_multi(const float* X, const float* const* Wp, floa
   MMSA_REQUIRE(!(any_bnrelu && stats));   // the folded form is for inference: no statistics wanted there
   ConvGeom g;
   if (fill_geom(g, B, H, W, Cin, Cout, ntable, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
+  {
+    // every problem either the whole 3x3 table or its centre tap alone: the strip-sharing kernel takes the launch
+    bool rows3 = uses_rows3(B, H, W, Cout, ntable, dh, dw);
+    for (int i = 0; rows3 && i < n; ++i) {
+      const bool whole = m.ntaps[i] == 9 && m.tap0[i] == 0;
+      const bool centre = m.ntaps[i] == 1 && dh[m.tap0[i]] == 0 && dw[m.tap0[i]] == 0;
+      rows3 = whole || centre;
+    }
+    if (rows3) {
+      Conv3Args a{};
+      a.n = n;
+      for (int i = 0; i < n; ++i) {
+        a.ntaps[i] = m.ntaps[i]; a.chunk0[i] = 0; a.chunk1[i] = Cin / KC;
+        a.Wp[i] = m.Wp[i]; a.Y[i] = m.Y[i]; a.stats[i] = m.stats[i]; a.bnrelu[i] = m.bnrelu[i];
+      }
+      a.second_z = -1;
+      return launch_igemm3(X, g, a, false, mmsa_stream(stream));
+    }
+  }
   float* st0 = stats ? stats[0] : nullptr;
   if (any_bnrelu) {
     const int tiles = mmsa_cdiv(H * W, 64);

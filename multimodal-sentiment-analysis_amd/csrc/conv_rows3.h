@@ -1,0 +1,469 @@
+// Implicit GEMM for the 3x3 / pad 1 convolutions (and their data gradients) that stages every input strip ONCE per
+// row of three taps.  Included by conv.hip inside its anonymous namespace (uses ConvGeom, KC, MAX_TAPS).
+//
+// Why: on this chip every global -> LDS request instruction (1 KiB per wave) holds its SIMD's issue for about 110
+// cycles, matrix instructions of the other resident wave included, so the number of requests per MFMA bounds the
+// kernel.  The general kernel (conv_igemm_kernel) fetches a fresh [BM rows][32 channels] input tile for each of the
+// nine taps.  The three taps of one kernel row (kh fixed, kw = -1, 0, +1) read the SAME run of flattened positions
+// shifted by one: position p of tap kw is X[p + dh*W + kw], and a run of BM + 2 positions holds all three.  Here the
+// K loop therefore walks  channel chunk -> tap row ("group") -> tap:  a group's strip of BM + 2 positions x 32
+// channels is requested once (into a ring of NA strips), each of its taps then only needs its weight tile (ring of
+// NB tiles, one per step), and the MFMA waves read the input fragments of tap kw from strip rows r + 1 + kw.
+// Requests per 3 taps and 64 x 64 tile: 9 + 24 instead of 48; for the 128 x 32 tile 17 + 12 instead of 60.
+//
+// Zero padding: a strip row whose flattened position falls outside the image reads as zero (buffer range check), which
+// covers the rows above / below the image once the column is valid; a shifted read that wraps into the neighbouring
+// image row (w + kw outside [0, W)) is zeroed per lane when the fragment is used.  No per-tap validity plan is needed,
+// so a workgroup's first request goes out a few hundred cycles after it starts.
+//
+// Step sequences (uniform per workgroup):  3x3: per chunk three groups of three taps [+ one single-tap group reading
+// the second operand pair X2 / Wp2];  1x1 (centre tap of the offset table, a problem of a multi-problem launch): per
+// chunk one single-tap group.  A problem's K loop may cover a sub-range of the channel chunks (a K range split over
+// two workgroups per tile).
+//
+// Pipeline: loader step s requests the weight tile of step s + 4 and, DA steps ahead of a group's first step, that
+// group's strip (DA = 4, together with the group's first weight tile; NA - 1 for the single-tap-only sequence, whose
+// strips would otherwise overwrite one still in use: a request may go out once the group NA back has been consumed,
+// i.e. the NA - 1 groups between must span at least DA steps; NA = 4 strips for 64-row tiles, 3 for 128-row tiles).
+// It then waits until everything step s + 2 reads has landed (requests complete in order, so
+// that is a bound on the outstanding count, derived from which of the later steps began a group) and joins the
+// barrier.  The MFMA waves mirror conv_igemm_kernel: fragments of half a chunk are read behind the first MFMA of the
+// previous half.
+
+struct Conv3Args {
+  int n;                       // problems of the launch (grid.z), at least 1
+  int ntaps[4];                // 9: rows of three taps;  1: the centre tap alone
+  int chunk0[4], chunk1[4];    // 32-channel chunks [chunk0, chunk1) a problem's K loop covers
+  const float* Wp[4];          // packed weights [ntaps][Cout][Cin]
+  float* Y[4];
+  float* stats[4];             // STATS instantiations
+  const float* bnrelu[4];      // BNRELU instantiations: [4][Cout] table or null
+  const float* X2;             // optional second operand pair (see conv_igemm_kernel)
+  const float* Wp2;
+  int second_z;                // problem whose K loop takes the second pair (-1: every 9-tap problem)
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm_at_most() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STATS, bool ACCUM, bool BNRELU>
+__global__ __launch_bounds__(512) void conv_igemm3_kernel(const float* __restrict__ X, const ConvGeom g,
+                                                          int tiles_per_img, const Conv3Args a) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 MFMA waves per workgroup (plus 4 loader waves)");
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold whole 32x32 MFMA tiles");
+  constexpr int SROWS = BM + 8;            // strip rows in LDS (BM + 2 used; whole 8-row request pieces)
+  constexpr int NPIECE = SROWS / 8;        // request instructions per strip
+  constexpr int AP0 = (NPIECE + 3) / 4;    // ... of which wave 0 issues AP0, the others AP0 or AP0 - 1
+  constexpr int B_LD = BN / 32;            // request instructions per wave for one weight tile
+  constexpr int STRIP = SROWS * KC, BBUF = BN * KC;
+  constexpr int NA = BM == 64 ? 4 : 3, NB = 5, D = NB - 1;
+  constexpr int OOB = 0x7ffffff0;
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [NA][SROWS][32] strips, then [NB][BN][32] weight tiles
+  LAB_STAMP(0);
+  const int z = blockIdx.z;
+  const bool p1 = a.ntaps[z] == 1;                                           // uniform
+  const bool dual = !p1 && a.X2 != nullptr && (a.second_z < 0 || z == a.second_z);
+  const float* __restrict__ Wp = a.Wp[z];
+  float* __restrict__ Y = a.Y[z];
+  const int chunk0 = a.chunk0[z];
+  const int ngrp = p1 ? 1 : (dual ? 4 : 3);
+  const int nsteps = (p1 ? 1 : (dual ? 10 : 9)) * (a.chunk1[z] - chunk0);
+  // A group's strip is requested DA steps ahead of its first step, as early as its weight tile (D) where the ring
+  // allows: the request overwrites the strip NA groups back, so the NA - 1 groups between must span at least DA steps
+  // (3x3 rows [+ one single]: >= 4 with three strips; single-tap groups only: NA - 1).
+  const int DA = p1 ? NA - 1 : D;
+  // offsets of the three tap rows and the column step of the first tap of a row (constant indices: scalar loads)
+  const int dh0 = g.dh[0], dh1 = g.dh[3], dh2 = g.dh[6], dwf = g.dw[0];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool loader = wave8 >= 4;
+  const int wave = wave8 & 3;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int HW = g.H * g.W;
+  const int b = blockIdx.x / tiles_per_img;
+  const int tile = blockIdx.x - b * tiles_per_img;
+  const int p0 = tile * BM;
+  const int n0 = blockIdx.y * BN;
+  typedef __attribute__((address_space(3))) void lds_void;
+  // Strip layout: consecutive flattened positions starting at p0 - 1, with one GAP row (zeros) after the last column
+  // of every image row.  A tap with column offset -1 at column 0 (or +1 at column W-1) then reads a gap instead of the
+  // neighbouring image row's pixel, so the shifted reads need no per-lane masking.  With w0 = column of position p0 - 1
+  // and row_start = first position of its image row, strip row u holds:  x = u + w0, q = x / (W+1), rem = x % (W+1):
+  // gap if rem == W, else position row_start + q W + rem.
+  const int f0 = p0 - 1;
+  const int w0 = f0 < 0 ? g.W - 1 : f0 % g.W;
+  const int row_start = f0 - w0;
+
+  auto group_taps = [&](int k) { return (p1 || k == 3) ? 1 : 3; };   // uniform
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (loader) {
+    const float* Xb = X + (long)b * HW * g.Cin;
+    const __amdgpu_buffer_rsrc_t rX =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xb), 0, HW * g.Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Wp), 0, (p1 ? 1 : 9) * g.Cout * g.Cin * 4, 0x00020000);
+    const float* X2b = dual ? a.X2 + (long)b * HW * g.Cin : Xb;
+    const __amdgpu_buffer_rsrc_t rX2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(X2b), 0, HW * g.Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(dual ? a.Wp2 : Wp), 0, g.Cout * g.Cin * 4, 0x00020000);
+    // Per-lane source plan.  Strip piece P (8 rows, P = wave, wave + 4, ...): lane l supplies strip row u = 8 P + (l >> 3),
+    // 16-byte slot l & 7 holding piece (l & 7) ^ ((u >> 1) & 7) of that row's position in the tap row's input line.  A
+    // position before the image gives a negative (= huge unsigned) offset, one past its end an offset beyond the
+    // buffer: both read as zero, and so does the fixed negative offset of a gap row.
+    const int lrow = lane >> 3, lslot = lane & 7;
+    int aoff[AP0], boff[B_LD];
+#pragma unroll
+    for (int j = 0; j < AP0; ++j) {
+      const int u = 8 * (wave + 4 * j) + lrow;
+      const int x = u + w0;
+      const int q = x / (g.W + 1), rem = x - q * (g.W + 1);
+      const int pos = row_start + q * g.W + rem;
+      aoff[j] = rem != g.W ? (pos * g.Cin + 4 * (lslot ^ ((u >> 1) & 7))) * 4 : -(1 << 30);
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      const int r = 8 * (wave + 4 * j) + lrow;
+      boff[j] = ((n0 + r) * g.Cin + 4 * (lslot ^ ((r >> 1) & 7))) * 4;
+    }
+    int apw = 0;   // strip pieces this wave issues (uniform)
+#pragma unroll
+    for (int j = 0; j < AP0; ++j) apw += (wave + 4 * j < NPIECE) ? 1 : 0;
+    const int row_bytes = g.W * g.Cin * 4;
+
+    // cursors (uniform): weight tiles step by step, strips group by group
+    int bq = 0, bc = chunk0, bk = 0, bj = 0, wbuf = 0;
+    int aq = 0, ac = chunk0, ak = 0, aslot = 0;
+    unsigned hist = 0;   // bit i: step bq - 1 - i began a group
+    LAB_STAMP_L(1);
+    for (int s = -D; s < nsteps; ++s) {
+      if (aq < nsteps && aq - DA == s) {
+        const bool second = ak == 3;
+        const int dh = p1 ? 0 : (ak == 0 ? dh0 : (ak == 1 ? dh1 : (ak == 2 ? dh2 : 0)));
+        float* base = lds + aslot * STRIP + wave * 256;
+#pragma unroll
+        for (int j = 0; j < AP0; ++j) {
+          if (wave + 4 * j < NPIECE) {   // uniform
+            const int va = aoff[j] + dh * row_bytes;
+            if (second)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lds_void*)(base + j * 1024), 16, va, ac * (KC * 4), 0, 0);
+            else
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void*)(base + j * 1024), 16, va, ac * (KC * 4), 0, 0);
+          }
+        }
+        aslot = aslot + 1 == NA ? 0 : aslot + 1;
+        aq += group_taps(ak);
+        if (++ak == ngrp) {
+          ak = 0;
+          ++ac;
+        }
+      }
+      {
+        const bool real = bq < nsteps;
+        float* base = lds + NA * STRIP + wbuf * BBUF + wave * 256;
+        const bool second = bk == 3;
+        const int sb = second ? bc * (KC * 4) : (((p1 ? 0 : 3 * bk + bj) * g.Cout * g.Cin + bc * KC) * 4);
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+          const int vb = real ? boff[j] : OOB;
+          if (second)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, (lds_void*)(base + j * 1024), 16, vb, sb, 0, 0);
+          else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void*)(base + j * 1024), 16, vb, sb, 0, 0);
+        }
+        hist = (hist << 1) | ((real && bj == 0) ? 1u : 0u);
+        wbuf = wbuf + 1 == NB ? 0 : wbuf + 1;
+        ++bq;
+        if (real) {
+          if (++bj == group_taps(bk)) {
+            bj = 0;
+            if (++bk == ngrp) {
+              bk = 0;
+              ++bc;
+            }
+          }
+        }
+      }
+      if (s >= -1) {
+        // now: hist bit 0 = step s+4 began a group, bit 1 = s+3, bit 2 = s+2, bit 3 = s+1.  Everything step s+2 reads
+        // must have landed; requests issued after its last one may stay outstanding.
+        // Issue order within a loader step: strip (of the group DA steps ahead), then weight tile (of step s+4).
+        //   DA = 4: younger than step s+2's last request are the tiles of s+3, s+4 and the strips of groups starting there
+        //   DA = 3: ... the tiles of s+3, s+4 and the strip of a group starting at s+3
+        //   DA = 2: if s+2 begins a group its strip went out in this step, only the tile of s+4 is younger; otherwise
+        //           the tiles of s+3, s+4 and the strip of a group starting at s+1
+        int allowed;
+        if (DA == 4)
+          allowed = 2 * B_LD + (int)(((hist >> 1) & 1u) + (hist & 1u)) * apw;
+        else if (DA == 3)
+          allowed = 2 * B_LD + (int)((hist >> 1) & 1u) * apw;
+        else
+          allowed = ((hist >> 2) & 1u) ? B_LD : 2 * B_LD + (int)((hist >> 3) & 1u) * apw;
+        if (allowed >= 2 * B_LD + 2 * AP0)
+          wait_vm_at_most<2 * B_LD + 2 * AP0>();
+        else if (allowed >= 2 * B_LD + 2 * AP0 - 2)
+          wait_vm_at_most<2 * B_LD + 2 * AP0 - 2>();
+        else if (allowed >= 2 * B_LD + AP0)
+          wait_vm_at_most<2 * B_LD + AP0>();
+        else if (allowed >= 2 * B_LD + AP0 - 1)
+          wait_vm_at_most<2 * B_LD + AP0 - 1>();
+        else if (allowed >= 2 * B_LD)
+          wait_vm_at_most<2 * B_LD>();
+        else
+          wait_vm_at_most<B_LD>();
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    // the trailing requests may still be writing LDS, which the statistics epilogue reuses
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  } else {
+    const int li = lane & 31, lh = lane >> 5;
+    // Fragment addresses.  Tap position J of a row group (J = 0, 1, 2: column offsets dwf, 0, -dwf; single-tap groups
+    // read like J = 1) reads strip row  u = strip row of the lane's own position + offset;  pre[J][i][g4] is the float
+    // offset of 16-byte piece 2 g4 + lh of that row inside a strip (XOR swizzle of the row applied).
+    int pre[3][TM][4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r = wm * WTM + i * 32 + li;
+      const int x = p0 + r - row_start;
+      const int q = x / g.W, rem = x - q * g.W;
+      const int ub = q * (g.W + 1) + rem - w0;
+#pragma unroll
+      for (int J = 0; J < 3; ++J) {
+        const int u = ub + dwf * (1 - J);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) pre[J][i][g4] = u * KC + 4 * ((2 * g4 + lh) ^ ((u >> 1) & 7));
+      }
+    }
+    const int swzb = (li >> 1) & 7;
+    const int b_row = NA * STRIP + (wn * WTN + li) * KC;
+    int pieceB[4];
+#pragma unroll
+    for (int gk = 0; gk < 4; ++gk) pieceB[gk] = 4 * ((2 * gk + lh) ^ swzb);
+    struct Frag {
+      f32x4 a[2][TM], b[2][TN];
+    };
+    auto read_half = [&](Frag& f, int slot, const int (&pj)[TM][4], int bbuf, int half) {
+      const float* As = lds + slot * STRIP;
+      const float* Bb = lds + bbuf * BBUF + b_row;
+#pragma unroll
+      for (int gk = 0; gk < 2; ++gk) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) f.a[gk][i] = *reinterpret_cast<const f32x4*>(As + pj[i][2 * half + gk]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) f.b[gk][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * KC + pieceB[2 * half + gk]);
+      }
+    };
+    auto mfma_steps = [&](const Frag& f, int s_begin, int s_end) {
+#pragma unroll
+      for (int s = s_begin; s < s_end; ++s) {
+        const int gk = s >> 2, e = s & 3;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[gk][i][e], f.b[gk][j][e], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+
+    Frag f0, f1;
+    int slot = 0, bbuf = 0;
+    // One step: the 16 MFMAs of tap position J on strip `slot` and weight tile `bbuf`; behind the first MFMA of each
+    // half go the LDS reads of the next half -- the second half of this step, then the first half of the next step
+    // (tap position JN on strip `nslot`).
+    auto step = [&](auto Jc, auto JNc, int nslot) {
+      constexpr int J = decltype(Jc)::value, JN = decltype(JNc)::value;
+      const int nbuf = bbuf + 1 == NB ? 0 : bbuf + 1;
+      mfma_steps(f0, 0, 1);
+      read_half(f1, slot, pre[J], bbuf, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_steps(f0, 1, 8);
+      mfma_steps(f1, 0, 1);
+      read_half(f0, nslot, pre[JN], nbuf, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_steps(f1, 1, 8);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      bbuf = nbuf;
+      slot = nslot;
+    };
+    using std::integral_constant;
+    const integral_constant<int, 0> J0;
+    const integral_constant<int, 1> J1;
+    const integral_constant<int, 2> J2;
+    auto next_slot = [&]() { return slot + 1 == NA ? 0 : slot + 1; };
+
+    __builtin_amdgcn_s_barrier();
+    const int nchunks = a.chunk1[z] - chunk0;
+    if (p1) {
+      read_half(f0, 0, pre[1], 0, 0);
+      LAB_STAMP(1);
+      for (int c = 0; c < nchunks; ++c) step(J1, J1, next_slot());
+    } else {
+      read_half(f0, 0, pre[0], 0, 0);
+      LAB_STAMP(1);
+      for (int c = 0; c < nchunks; ++c) {
+#pragma unroll 1
+        for (int k = 0; k < 3; ++k) {
+          step(J0, J1, slot);
+          step(J1, J2, slot);
+          if (k == 2 && dual)
+            step(J2, J1, next_slot());   // the second pair's single tap follows
+          else
+            step(J2, J0, next_slot());
+        }
+        if (dual) step(J1, J0, next_slot());
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+
+  LAB_STAMP(2);
+  // epilogue (as conv_igemm_kernel): D[row][col]: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int li = lane & 31, lh = lane >> 5;
+  float* Yb = Y + (long)b * HW * g.Cout;
+  const float* __restrict__ ep = BNRELU ? a.bnrelu[z] : nullptr;   // uniform
+  float csum[TN], csq[TN], esc[TN], esh[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    csum[j] = csq[j] = 0.f;
+    esc[j] = 1.f;
+    esh[j] = 0.f;
+    if (BNRELU && ep) {
+      const int col = n0 + wn * WTN + j * 32 + li;
+      esc[j] = ep[2 * g.Cout + col];
+      esh[j] = ep[3 * g.Cout + col];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WTN + j * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int p = p0 + row;
+        if (p < HW && !loader) {
+          const float raw = acc[i][j][r];
+          const float v = BNRELU && ep ? fmaxf(fmaf(raw, esc[j], esh[j]), 0.f) : raw;
+          float* dst = Yb + (long)p * g.Cout + col;
+          if (ACCUM) {
+            unsafeAtomicAdd(dst, v);   // two writers at most onto a zeroed map: order-independent
+          } else {
+            *dst = v;
+          }
+          if (STATS) {
+            csum[j] += raw;
+            csq[j] = fmaf(raw, raw, csq[j]);
+          }
+        }
+      }
+    }
+  if (STATS) {
+    float* red = lds;   // safe: every wave passed the loop's final barrier
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      csum[j] += __shfl_xor(csum[j], 32, 64);
+      csq[j] += __shfl_xor(csq[j], 32, 64);
+      if (lh == 0 && !loader) {
+        red[(wm * 2 + 0) * BN + wn * WTN + j * 32 + li] = csum[j];
+        red[(wm * 2 + 1) * BN + wn * WTN + j * 32 + li] = csq[j];
+      }
+    }
+    __syncthreads();
+    if (t < 2 * BN) {
+      const int which = t / BN, col = t - which * BN;
+      float s = 0.f;
+#pragma unroll
+      for (int m = 0; m < WAVES_M; ++m) s += red[(m * 2 + which) * BN + col];
+      float* st = a.stats[z];
+      st[((long)which * g.Cout + n0 + col) * gridDim.x + blockIdx.x] = s;
+    }
+  }
+  LAB_STAMP(3);
+}
+
+// Whether an offset table is the 3x3 pattern this kernel walks: taps in three rows of three, one row offset per row,
+// column offsets (c, 0, -c) with c = +-1 in every row.
+static bool rows3_pattern(int ntaps, const int* dh, const int* dw) {
+  if (ntaps != 9) return false;
+  const int c = dw[0];
+  if (c != 1 && c != -1) return false;
+  for (int k = 0; k < 3; ++k) {
+    if (dh[3 * k] < -1 || dh[3 * k] > 1) return false;
+    for (int j = 0; j < 3; ++j)
+      if (dh[3 * k + j] != dh[3 * k] || dw[3 * k + j] != c * (1 - j)) return false;
+  }
+  return true;
+}
+
+// Which launches take this kernel.  Measured at batch 32 (tools/lab_rows3.sh): the 128 x 32 tile (data gradient into a
+// 32-channel map, where the input tile is 80 % of the requests) gains 18 % (48.0 -> 39.5 us); the 64 x 64 tile, with two
+// workgroups per CU, does not gain from fewer requests (3-8 % slower than the general kernel, whose rows of
+// consecutive positions also keep every ds_read_b128 lane group conflict free, which the gap rows here do not).
+// MMSA_IGEMM3 = 0: never; 1 (default): 32-wide results only; 2: every eligible launch (A/B aid).
+// (read at every launch, so a test can switch within one process)
+static int rows3_mode() {
+  const char* e = getenv("MMSA_IGEMM3");
+  const int mode = e ? atoi(e) : 1;
+  return mode < 0 || mode > 2 ? 1 : mode;
+}
+
+template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM, bool BNRELU>
+int launch_igemm3_inst(const float* X, const ConvGeom& g, const Conv3Args& a, hipStream_t s) {
+  constexpr size_t shmem = ((BM == 64 ? 4 : 3) * (size_t)(BM + 8) + 5 * (size_t)BN) * KC * sizeof(float);
+  static bool attr_set = false;
+  if (shmem > 48 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WM_, WN_, STATS, ACCUM, BNRELU>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
+      return MMSA_ERR_LAUNCH;
+    attr_set = true;
+  }
+  const int tiles = mmsa_cdiv((long)g.H * g.W, BM);
+  dim3 grid(g.B * tiles, g.Cout / BN, a.n);
+  hipLaunchKernelGGL((conv_igemm3_kernel<BM, BN, WM_, WN_, STATS, ACCUM, BNRELU>), grid, dim3(512), shmem, s, X, g, tiles,
+                     a);
+  return mmsa_launch_status();
+}
+
+// Picks the instantiation: statistics epilogue (every problem has a statistics buffer), atomic accumulation, folded
+// BatchNorm + ReLU (any problem has a table).  Cout % 64 != 0 selects the 128 x 32 tile (no statistics there).
+static int launch_igemm3(const float* X, const ConvGeom& g, const Conv3Args& a, bool accumulate, hipStream_t s) {
+  if ((long)g.H * g.W * g.Cin * 4 >= (1L << 30)) return MMSA_ERR_LIMIT;   // byte offsets within an image are 32-bit
+  const bool stats = a.stats[0] != nullptr;
+  bool bnrelu = false;
+  for (int i = 0; i < a.n; ++i) bnrelu = bnrelu || a.bnrelu[i];
+  if (g.Cout % 64 != 0) {
+    if (stats || bnrelu) return MMSA_ERR_ARG;
+    if (accumulate) return launch_igemm3_inst<128, 32, 4, 1, false, true, false>(X, g, a, s);
+    return launch_igemm3_inst<128, 32, 4, 1, false, false, false>(X, g, a, s);
+  }
+  if (bnrelu) {
+    if (stats || accumulate) return MMSA_ERR_ARG;
+    return launch_igemm3_inst<64, 64, 2, 2, false, false, true>(X, g, a, s);
+  }
+  if (stats) {
+    if (accumulate) return MMSA_ERR_ARG;
+    return launch_igemm3_inst<64, 64, 2, 2, true, false, false>(X, g, a, s);
+  }
+  if (accumulate) return launch_igemm3_inst<64, 64, 2, 2, false, true, false>(X, g, a, s);
+  return launch_igemm3_inst<64, 64, 2, 2, false, false, false>(X, g, a, s);
+}

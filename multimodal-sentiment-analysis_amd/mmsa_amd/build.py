@@ -32,7 +32,7 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = (os.path.join(CSRC, "mmsa_common.h"), os.path.join(CSRC, "fft512.h"))
+    headers = tuple(os.path.join(CSRC, h) for h in ("mmsa_common.h", "fft512.h", "conv_rows3.h"))
     jobs = []
     objs = []
     for src in SOURCES:

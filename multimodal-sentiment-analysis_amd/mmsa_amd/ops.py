@@ -43,10 +43,15 @@ def _prof_begin(kind: str, flops: float):
     return e
 
 
-def _igemm_name(bm, bn, stats, accum, geom, kchunks, nproblems=1, bnrelu=False) -> str:
+def _igemm_name(bm, bn, stats, accum, geom, kchunks, nproblems=1, bnrelu=False, offsets=None) -> str:
     """Name of the kernel instantiation mmsa_conv_fwd launches for this tile (as rocprofv3 prints it, without spaces);
-    kchunks = 32-channel chunks in a tile's K loop."""
+    kchunks = 32-channel chunks in a tile's K loop; offsets = the launch's (dh, dw) table."""
     wm, wn = (4, 1) if bn == 32 else (2, 2)
+    if offsets is not None and _lib.query("mmsa_conv_shares_tap_rows", *geom, len(offsets), _iarr([o[0] for o in offsets]),
+                                          _iarr([o[1] for o in offsets])):
+        return "conv_igemm3_kernel<%d,%d,%d,%d,%s,%s,%s>" % (bm, bn, wm, wn, "true" if stats else "false",
+                                                              "true" if accum else "false",
+                                                              "true" if bnrelu else "false")
     ring = _lib.query("mmsa_conv_ring_buffers", *geom, nproblems, kchunks)
     return "conv_igemm_kernel<%d,%d,%d,%d,%s,%s,%d,%s>" % (bm, bn, wm, wn, "true" if stats else "false",
                                                             "true" if accum else "false", ring,
@@ -255,7 +260,8 @@ def conv_fwd(X, Wp, Y, stats, B, H, W, Cin, Cout, taps, negate=False, accumulate
     ev = None
     if PROFILE is not None:
         bm, bn = (128, 32) if Cout % 64 else (conv_tile_rows(B, H, W, Cout), 64)
-        kind = _igemm_name(bm, bn, stats is not None, accumulate, (B, H, W, Cout), len(taps) * Cin // 32)
+        kind = _igemm_name(bm, bn, stats is not None, accumulate, (B, H, W, Cout), len(taps) * Cin // 32,
+                           offsets=[(sgn * t[0], sgn * t[1]) for t in taps])
         ev = _prof_begin(kind, 2.0 * B * H * W * Cin * Cout * len(taps))
     _lib.call("mmsa_conv_fwd", _chk(X), _chk(Wp), _chk(Y), _opt(stats), B, H, W, Cin, Cout, len(taps),
               _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), int(accumulate), _stream())
@@ -272,7 +278,8 @@ def conv_fwd_dual(X, Wp, X2, Wp2, Y, B, H, W, Cin, Cout, taps, negate=False):
     ev = None
     if PROFILE is not None:
         bm, bn = (128, 32) if Cout % 64 else (conv_tile_rows(B, H, W, Cout), 64)
-        ev = _prof_begin(_igemm_name(bm, bn, False, False, (B, H, W, Cout), (len(taps) + 1) * Cin // 32),
+        ev = _prof_begin(_igemm_name(bm, bn, False, False, (B, H, W, Cout), (len(taps) + 1) * Cin // 32,
+                                     offsets=[(sgn * t[0], sgn * t[1]) for t in taps]),
                          2.0 * B * H * W * Cin * Cout * (len(taps) + 1))
     _lib.call("mmsa_conv_fwd_dual", _chk(X), _chk(Wp), _chk(X2), _chk(Wp2), _chk(Y), B, H, W, Cin, Cout, len(taps),
               _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), _stream())
@@ -293,8 +300,8 @@ def conv_fwd_dual_split(X, Wp, X2, Wp2, Y, B, H, W, Cin, Cout, taps, negate=Fals
     sgn = -1 if negate else 1
     ev = None
     if PROFILE is not None:
-        ring = _lib.query("mmsa_conv_ring_buffers", B, H, W, Cout, 2, (len(taps) + 1) * Cin // 32)
-        ev = _prof_begin("conv_igemm_kernel<64,64,2,2,false,true,%d,false>" % ring,
+        ev = _prof_begin(_igemm_name(64, 64, False, True, (B, H, W, Cout), (len(taps) + 1) * Cin // 32, 2,
+                                     offsets=[(sgn * t[0], sgn * t[1]) for t in taps]),
                          2.0 * B * H * W * Cin * Cout * (len(taps) + 1))
     _lib.call("mmsa_conv_fwd_dual_split", _chk(X), _chk(Wp), _chk(X2), _chk(Wp2), _chk(Y), B, H, W, Cin, Cout,
               len(taps), _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), _stream())
@@ -327,7 +334,9 @@ def conv_fwd_multi(X, Wps, Ys, ntaps_list, B, H, W, Cin, Cout, taps, tap0_list=N
     ev = None
     if PROFILE is not None:
         ev = _prof_begin(_igemm_name(bm, 64, stats_list is not None, False, (B, H, W, Cout), len(taps) * Cin // 32, n,
-                                     bnrelu_list is not None and any(c is not None for c in bnrelu_list)),
+                                     bnrelu_list is not None and any(c is not None for c in bnrelu_list),
+                                     offsets=list(taps) if all(
+                                         (nt, t0) in ((9, 0), (1, 4)) for nt, t0 in zip(ntaps_list, tap0_list)) else None),
                          2.0 * B * H * W * Cin * Cout * sum(ntaps_list))
     _lib.call("mmsa_conv_fwd_multi", _chk(X), _parr([_chk(w) for w in Wps]), _parr([_chk(y) for y in Ys]),
               _iarr(ntaps_list), _iarr(tap0_list), None if stats_list is None else _parr([_chk(t) for t in stats_list]),
