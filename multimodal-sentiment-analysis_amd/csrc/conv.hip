@@ -887,10 +887,7 @@ static int pick_bm(int B, int H, int W, int Cout) {
 static bool uses_rows3(int B, int H, int W, int Cout, int ntaps, const int* dh, const int* dw) {
   const int mode = rows3_mode();
   if (!mode || !rows3_pattern(ntaps, dh, dw)) return false;
-  if (Cout % 64 == 0 && (mode < 2 || pick_bm(B, H, W, Cout) != 64)) return false;
-  // a strip has BM + 8 rows: BM + 2 positions plus one gap row per image-row end it spans (1 + (BM-1)/W at most)
-  const int bm = Cout % 64 ? 128 : 64;
-  return (bm - 1) / W <= 5;
+  return Cout % 64 != 0 || (mode == 2 && pick_bm(B, H, W, Cout) == 64);
 }
 
 MMSA_EXPORT int mmsa_conv_shares_tap_rows(int B, int H, int W, int Cout, int ntaps, const int* dh, const int* dw) {

@@ -12,23 +12,25 @@
 // Requests per 3 taps and 64 x 64 tile: 9 + 24 instead of 48; for the 128 x 32 tile 17 + 12 instead of 60.
 //
 // Zero padding: a strip row whose flattened position falls outside the image reads as zero (buffer range check), which
-// covers the rows above / below the image once the column is valid; a shifted read that wraps into the neighbouring
-// image row (w + kw outside [0, W)) is zeroed per lane when the fragment is used.  No per-tap validity plan is needed,
-// so a workgroup's first request goes out a few hundred cycles after it starts.
+// covers the rows above / below the image once the column is valid.  A shifted read that would wrap into the
+// neighbouring image row (w + kw outside [0, W)) is pointed at a strip row that always holds zeros instead (row BM + 2):
+// the redirection is part of the per-lane fragment addresses computed once per workgroup, so the K loop has no
+// masking and no per-tap validity plan, and a workgroup's first request goes out a few hundred cycles after it starts.
 //
 // Step sequences (uniform per workgroup):  3x3: per chunk three groups of three taps [+ one single-tap group reading
 // the second operand pair X2 / Wp2];  1x1 (centre tap of the offset table, a problem of a multi-problem launch): per
 // chunk one single-tap group.  A problem's K loop may cover a sub-range of the channel chunks (a K range split over
 // two workgroups per tile).
 //
-// Pipeline: loader step s requests the weight tile of step s + 4 and, DA steps ahead of a group's first step, that
-// group's strip (DA = 4, together with the group's first weight tile; NA - 1 for the single-tap-only sequence, whose
-// strips would otherwise overwrite one still in use: a request may go out once the group NA back has been consumed,
-// i.e. the NA - 1 groups between must span at least DA steps; NA = 4 strips for 64-row tiles, 3 for 128-row tiles).
-// It then waits until everything step s + 2 reads has landed (requests complete in order, so
-// that is a bound on the outstanding count, derived from which of the later steps began a group) and joins the
-// barrier.  The MFMA waves mirror conv_igemm_kernel: fragments of half a chunk are read behind the first MFMA of the
-// previous half.
+// Pipeline: loader step s requests the weight tile of step s + 4 and, when a group begins at step s + 4, that group's
+// strip ahead of it (single-tap-only sequence: the strip of step s + 3; its strips come one per step, and a request
+// overwrites the strip NA groups back, so the NA - 1 groups between must span the look-ahead: NA = 4 strips for 64-row
+// tiles, 3 for 128-row tiles, which never run that sequence).  It then waits until everything step s + 2 reads has
+// landed -- requests complete in order, so that is a bound on the outstanding count, known statically for each
+// position of the step sequence -- and joins the barrier.  The three step sequences are written out as three loops
+// without cursors or branches inside: the loader wave's scalar bookkeeping sits on the critical path once the
+// requests themselves are few.  The MFMA waves mirror conv_igemm_kernel: fragments of half a chunk are read behind
+// the first MFMA of the previous half.
 
 struct Conv3Args {
   int n;                       // problems of the launch (grid.z), at least 1
@@ -73,10 +75,6 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const float* __restric
   const int chunk0 = a.chunk0[z];
   const int ngrp = p1 ? 1 : (dual ? 4 : 3);
   const int nsteps = (p1 ? 1 : (dual ? 10 : 9)) * (a.chunk1[z] - chunk0);
-  // A group's strip is requested DA steps ahead of its first step, as early as its weight tile (D) where the ring
-  // allows: the request overwrites the strip NA groups back, so the NA - 1 groups between must span at least DA steps
-  // (3x3 rows [+ one single]: >= 4 with three strips; single-tap groups only: NA - 1).
-  const int DA = p1 ? NA - 1 : D;
   // offsets of the three tap rows and the column step of the first tap of a row (constant indices: scalar loads)
   const int dh0 = g.dh[0], dh1 = g.dh[3], dh2 = g.dh[6], dwf = g.dw[0];
 
@@ -92,14 +90,9 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const float* __restric
   const int p0 = tile * BM;
   const int n0 = blockIdx.y * BN;
   typedef __attribute__((address_space(3))) void lds_void;
-  // Strip layout: consecutive flattened positions starting at p0 - 1, with one GAP row (zeros) after the last column
-  // of every image row.  A tap with column offset -1 at column 0 (or +1 at column W-1) then reads a gap instead of the
-  // neighbouring image row's pixel, so the shifted reads need no per-lane masking.  With w0 = column of position p0 - 1
-  // and row_start = first position of its image row, strip row u holds:  x = u + w0, q = x / (W+1), rem = x % (W+1):
-  // gap if rem == W, else position row_start + q W + rem.
+  // Strip layout: row u holds flattened position p0 - 1 + u of the tap row's input line for u < BM + 2; the rows
+  // behind them are always requested out of range and therefore hold zeros.
   const int f0 = p0 - 1;
-  const int w0 = f0 < 0 ? g.W - 1 : f0 % g.W;
-  const int row_start = f0 - w0;
 
   auto group_taps = [&](int k) { return (p1 || k == 3) ? 1 : 3; };   // uniform
 
@@ -125,108 +118,158 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const float* __restric
     // Per-lane source plan.  Strip piece P (8 rows, P = wave, wave + 4, ...): lane l supplies strip row u = 8 P + (l >> 3),
     // 16-byte slot l & 7 holding piece (l & 7) ^ ((u >> 1) & 7) of that row's position in the tap row's input line.  A
     // position before the image gives a negative (= huge unsigned) offset, one past its end an offset beyond the
-    // buffer: both read as zero, and so does the fixed negative offset of a gap row.
+    // buffer: both read as zero, and so does the fixed negative offset of the zero rows behind the strip.
     const int lrow = lane >> 3, lslot = lane & 7;
     int aoff[AP0], boff[B_LD];
 #pragma unroll
     for (int j = 0; j < AP0; ++j) {
       const int u = 8 * (wave + 4 * j) + lrow;
-      const int x = u + w0;
-      const int q = x / (g.W + 1), rem = x - q * (g.W + 1);
-      const int pos = row_start + q * g.W + rem;
-      aoff[j] = rem != g.W ? (pos * g.Cin + 4 * (lslot ^ ((u >> 1) & 7))) * 4 : -(1 << 30);
+      aoff[j] = u < BM + 2 ? ((f0 + u) * g.Cin + 4 * (lslot ^ ((u >> 1) & 7))) * 4 : -(1 << 30);
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
       const int r = 8 * (wave + 4 * j) + lrow;
       boff[j] = ((n0 + r) * g.Cin + 4 * (lslot ^ ((r >> 1) & 7))) * 4;
     }
-    int apw = 0;   // strip pieces this wave issues (uniform)
-#pragma unroll
-    for (int j = 0; j < AP0; ++j) apw += (wave + 4 * j < NPIECE) ? 1 : 0;
     const int row_bytes = g.W * g.Cin * 4;
+    const int nchunks = a.chunk1[z] - chunk0;
 
-    // cursors (uniform): weight tiles step by step, strips group by group
-    int bq = 0, bc = chunk0, bk = 0, bj = 0, wbuf = 0;
-    int aq = 0, ac = chunk0, ak = 0, aslot = 0;
-    unsigned hist = 0;   // bit i: step bq - 1 - i began a group
-    LAB_STAMP_L(1);
-    for (int s = -D; s < nsteps; ++s) {
-      if (aq < nsteps && aq - DA == s) {
-        const bool second = ak == 3;
-        const int dh = p1 ? 0 : (ak == 0 ? dh0 : (ak == 1 ? dh1 : (ak == 2 ? dh2 : 0)));
-        float* base = lds + aslot * STRIP + wave * 256;
+    // Request helpers.  Uniform values are pinned to scalar registers (readfirstlane): where the compiler's divergence
+    // analysis loses track of one, it wraps every request in a loop over the distinct values of its scalar offset.
+    int slot_w = 0, buf_w = 0;   // ring positions the next strip / weight tile is written to
+    // strip of tap row k (0..2; 3: the second operand pair) of channel chunk c (relative to chunk0); !real: past the end of
+    // the K loop, the instructions still issue (the waits below count them) but fetch nothing
+    auto strip = [&](int c, int k, bool real) {
+      const bool second = k == 3;
+      const int dh = p1 ? 0 : (k == 0 ? dh0 : (k == 1 ? dh1 : (k == 2 ? dh2 : 0)));
+      const int dshift = __builtin_amdgcn_readfirstlane(dh * row_bytes);
+      const int soff = __builtin_amdgcn_readfirstlane((chunk0 + c) * (KC * 4));
+      float* base = lds + __builtin_amdgcn_readfirstlane(slot_w * STRIP + wave * 256);
 #pragma unroll
-        for (int j = 0; j < AP0; ++j) {
-          if (wave + 4 * j < NPIECE) {   // uniform
-            const int va = aoff[j] + dh * row_bytes;
-            if (second)
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lds_void*)(base + j * 1024), 16, va, ac * (KC * 4), 0, 0);
-            else
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void*)(base + j * 1024), 16, va, ac * (KC * 4), 0, 0);
-          }
-        }
-        aslot = aslot + 1 == NA ? 0 : aslot + 1;
-        aq += group_taps(ak);
-        if (++ak == ngrp) {
-          ak = 0;
-          ++ac;
-        }
-      }
-      {
-        const bool real = bq < nsteps;
-        float* base = lds + NA * STRIP + wbuf * BBUF + wave * 256;
-        const bool second = bk == 3;
-        const int sb = second ? bc * (KC * 4) : (((p1 ? 0 : 3 * bk + bj) * g.Cout * g.Cin + bc * KC) * 4);
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j) {
-          const int vb = real ? boff[j] : OOB;
+      for (int j = 0; j < AP0; ++j) {
+        if (wave + 4 * j < NPIECE) {   // uniform
+          const int va = real ? aoff[j] + dshift : OOB;
           if (second)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, (lds_void*)(base + j * 1024), 16, vb, sb, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lds_void*)(base + j * 1024), 16, va, soff, 0, 0);
           else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void*)(base + j * 1024), 16, vb, sb, 0, 0);
-        }
-        hist = (hist << 1) | ((real && bj == 0) ? 1u : 0u);
-        wbuf = wbuf + 1 == NB ? 0 : wbuf + 1;
-        ++bq;
-        if (real) {
-          if (++bj == group_taps(bk)) {
-            bj = 0;
-            if (++bk == ngrp) {
-              bk = 0;
-              ++bc;
-            }
-          }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void*)(base + j * 1024), 16, va, soff, 0, 0);
         }
       }
-      if (s >= -1) {
-        // now: hist bit 0 = step s+4 began a group, bit 1 = s+3, bit 2 = s+2, bit 3 = s+1.  Everything step s+2 reads
-        // must have landed; requests issued after its last one may stay outstanding.
-        // Issue order within a loader step: strip (of the group DA steps ahead), then weight tile (of step s+4).
-        //   DA = 4: younger than step s+2's last request are the tiles of s+3, s+4 and the strips of groups starting there
-        //   DA = 3: ... the tiles of s+3, s+4 and the strip of a group starting at s+3
-        //   DA = 2: if s+2 begins a group its strip went out in this step, only the tile of s+4 is younger; otherwise
-        //           the tiles of s+3, s+4 and the strip of a group starting at s+1
-        int allowed;
-        if (DA == 4)
-          allowed = 2 * B_LD + (int)(((hist >> 1) & 1u) + (hist & 1u)) * apw;
-        else if (DA == 3)
-          allowed = 2 * B_LD + (int)((hist >> 1) & 1u) * apw;
+      slot_w = slot_w + 1 == NA ? 0 : slot_w + 1;
+    };
+    // weight tile of tap `tap` (0..8 of the problem's packed weights; -1: the second pair's) for channel chunk c
+    auto wtile = [&](int c, int tap, bool real) {
+      const bool second = tap < 0;
+      const int sb = __builtin_amdgcn_readfirstlane(
+          second ? (chunk0 + c) * (KC * 4) : ((tap * g.Cout * g.Cin + (chunk0 + c) * KC) * 4));
+      float* base = lds + __builtin_amdgcn_readfirstlane(NA * STRIP + buf_w * BBUF + wave * 256);
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j) {
+        const int vb = real ? boff[j] : OOB;
+        if (second)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, (lds_void*)(base + j * 1024), 16, vb, sb, 0, 0);
         else
-          allowed = ((hist >> 2) & 1u) ? B_LD : 2 * B_LD + (int)((hist >> 3) & 1u) * apw;
-        if (allowed >= 2 * B_LD + 2 * AP0)
-          wait_vm_at_most<2 * B_LD + 2 * AP0>();
-        else if (allowed >= 2 * B_LD + 2 * AP0 - 2)
-          wait_vm_at_most<2 * B_LD + 2 * AP0 - 2>();
-        else if (allowed >= 2 * B_LD + AP0)
-          wait_vm_at_most<2 * B_LD + AP0>();
-        else if (allowed >= 2 * B_LD + AP0 - 1)
-          wait_vm_at_most<2 * B_LD + AP0 - 1>();
-        else if (allowed >= 2 * B_LD)
-          wait_vm_at_most<2 * B_LD>();
-        else
-          wait_vm_at_most<B_LD>();
-        __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_void*)(base + j * 1024), 16, vb, sb, 0, 0);
+      }
+      buf_w = buf_w + 1 == NB ? 0 : buf_w + 1;
+    };
+    // End of loader step s: everything step s + 2 reads must have landed.  Requests complete in issue order, so that is
+    // "at most N requests outstanding", N = this wave's requests issued after the last one step s + 2 needs: the weight
+    // tiles of steps s + 3 and s + 4 plus NSTRIPS strips (those of groups that begin at s + 3 or s + 4; wave 0 issues
+    // AP0 pieces per strip, the others AP0 - 1 when the strip's piece count is 1 modulo 4).  Then the barrier.
+    const bool full = wave + 4 * (AP0 - 1) < NPIECE;   // this wave issues AP0 pieces per strip (uniform)
+    auto publish = [&](auto nstrips_c) {
+      constexpr int NS = decltype(nstrips_c)::value;
+      if (full)
+        wait_vm_at_most<2 * B_LD + NS * AP0>();
+      else
+        wait_vm_at_most<2 * B_LD + NS * (AP0 - 1)>();
+      __builtin_amdgcn_s_barrier();
+    };
+    const std::integral_constant<int, 0> S0;
+    const std::integral_constant<int, 1> S1;
+    const std::integral_constant<int, 2> S2;
+    LAB_STAMP_L(1);
+    if (p1) {
+      // single-tap groups: a strip per step, requested three steps ahead (the ring of NA = 4 strips allows no more)
+      wtile(0, 0, true);
+      strip(0, 0, true);
+      wtile(1, 0, 1 < nchunks);
+      strip(1, 0, 1 < nchunks);
+      wtile(2, 0, 2 < nchunks);
+      strip(2, 0, 2 < nchunks);
+      wtile(3, 0, 3 < nchunks);
+      publish(S1);
+#pragma unroll 1
+      for (int s = 0; s < nchunks; ++s) {
+        strip(s + 3, 0, s + 3 < nchunks);
+        wtile(s + 4, 0, s + 4 < nchunks);
+        publish(S1);
+      }
+    } else if (!dual) {
+      // groups of three taps, G = 3 per chunk; group index -> (chunk, tap row) kept for the groups one and two ahead
+      const int G = 3 * nchunks;
+      int c1 = 0, k1 = 1, c2 = 0, k2 = 2;   // groups 1 and 2 (every chunk has three groups)
+      strip(0, 0, true);
+      wtile(0, 0, true);
+      wtile(0, 1, true);
+      wtile(0, 2, true);
+      strip(c1, k1, true);
+      wtile(c1, 3 * k1, true);
+      publish(S1);
+#pragma unroll 1
+      for (int grp = 0; grp < G; ++grp) {
+        const bool r1 = grp + 1 < G, r2 = grp + 2 < G;
+        wtile(c1, 3 * k1 + 1, r1);
+        publish(S1);
+        wtile(c1, 3 * k1 + 2, r1);
+        publish(S0);
+        strip(c2, k2, r2);
+        wtile(c2, 3 * k2, r2);
+        publish(S1);
+        c1 = c2;
+        k1 = k2;
+        if (++k2 == 3) {
+          k2 = 0;
+          ++c2;
+        }
+      }
+    } else {
+      // per chunk: tap rows at steps 0, 3, 6 and the second pair's single tap at step 9
+      strip(0, 0, true);
+      wtile(0, 0, true);
+      wtile(0, 1, true);
+      wtile(0, 2, true);
+      strip(0, 1, true);
+      wtile(0, 3, true);
+      publish(S1);
+#pragma unroll 1
+      for (int c = 0; c < nchunks; ++c) {
+        const bool rn = c + 1 < nchunks;
+        wtile(c, 4, true);
+        publish(S1);
+        wtile(c, 5, true);
+        publish(S0);
+        strip(c, 2, true);
+        wtile(c, 6, true);
+        publish(S1);
+        wtile(c, 7, true);
+        publish(S1);
+        wtile(c, 8, true);
+        publish(S0);
+        strip(c, 3, true);
+        wtile(c, -1, true);
+        publish(S1);
+        strip(c + 1, 0, rn);
+        wtile(c + 1, 0, rn);
+        publish(S2);
+        wtile(c + 1, 1, rn);
+        publish(S1);
+        wtile(c + 1, 2, rn);
+        publish(S0);
+        strip(c + 1, 1, rn);
+        wtile(c + 1, 3, rn);
+        publish(S1);
       }
     }
     // the trailing requests may still be writing LDS, which the statistics epilogue reuses
@@ -241,12 +284,12 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const float* __restric
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int r = wm * WTM + i * 32 + li;
-      const int x = p0 + r - row_start;
-      const int q = x / g.W, rem = x - q * g.W;
-      const int ub = q * (g.W + 1) + rem - w0;
+      const int wcol = (p0 + r) % g.W;
 #pragma unroll
       for (int J = 0; J < 3; ++J) {
-        const int u = ub + dwf * (1 - J);
+        const int dw = dwf * (1 - J);
+        const bool wraps = (dw < 0 && wcol == 0) || (dw > 0 && wcol == g.W - 1);
+        const int u = wraps ? BM + 2 : r + 1 + dw;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) pre[J][i][g4] = u * KC + 4 * ((2 * g4 + lh) ^ ((u >> 1) & 7));
       }
@@ -315,21 +358,35 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const float* __restric
     if (p1) {
       read_half(f0, 0, pre[1], 0, 0);
       LAB_STAMP(1);
+#pragma unroll 1
       for (int c = 0; c < nchunks; ++c) step(J1, J1, next_slot());
     } else {
       read_half(f0, 0, pre[0], 0, 0);
       LAB_STAMP(1);
-      for (int c = 0; c < nchunks; ++c) {
+      // One loop per step sequence, each without a branch inside its body: where paths through the loop body merge,
+      // the compiler parks the accumulator in another register tuple and copies all sixteen registers back (behind a
+      // wait for the matrix pipe to drain) on every trip.
+      if (!dual) {
 #pragma unroll 1
-        for (int k = 0; k < 3; ++k) {
+        for (int grp = 0; grp < 3 * nchunks; ++grp) {
           step(J0, J1, slot);
           step(J1, J2, slot);
-          if (k == 2 && dual)
-            step(J2, J1, next_slot());   // the second pair's single tap follows
-          else
-            step(J2, J0, next_slot());
+          step(J2, J0, next_slot());
         }
-        if (dual) step(J1, J0, next_slot());
+      } else {
+#pragma unroll 1
+        for (int c = 0; c < nchunks; ++c) {
+          step(J0, J1, slot);
+          step(J1, J2, slot);
+          step(J2, J0, next_slot());
+          step(J0, J1, slot);
+          step(J1, J2, slot);
+          step(J2, J0, next_slot());
+          step(J0, J1, slot);
+          step(J1, J2, slot);
+          step(J2, J1, next_slot());   // the second pair's single tap follows
+          step(J1, J0, next_slot());
+        }
       }
     }
     __builtin_amdgcn_s_barrier();
@@ -415,16 +472,18 @@ static bool rows3_pattern(int ntaps, const int* dh, const int* dw) {
   return true;
 }
 
-// Which launches take this kernel.  Measured at batch 32 (tools/lab_rows3.sh): the 128 x 32 tile (data gradient into a
-// 32-channel map, where the input tile is 80 % of the requests) gains 18 % (48.0 -> 39.5 us); the 64 x 64 tile, with two
-// workgroups per CU, does not gain from fewer requests (3-8 % slower than the general kernel, whose rows of
-// consecutive positions also keep every ds_read_b128 lane group conflict free, which the gap rows here do not).
-// MMSA_IGEMM3 = 0: never; 1 (default): 32-wide results only; 2: every eligible launch (A/B aid).
-// (read at every launch, so a test can switch within one process)
+// Which launches take this kernel.  Measured at batch 32 against the general kernel (tools/lab_rows3.sh, kernel alone):
+// forward 32->64 36.4 -> 34.5 us, 64->64 61.8 -> 56.7, 64->128 29.1 -> 26.0, 128->128 49.7 -> 44.9 (108 TFLOP/s),
+// 128->256 31.6 -> 26.1, 256->256 55.7 -> 46.0 (105 TFLOP/s); data gradient 64->32 (128 x 32 tile) 48.5 -> 35.6,
+// 256->128 53.1 -> 42.4.  (The first versions of this kernel were SLOWER than the general one although they issued a
+// third fewer requests: a loader wave that walks the step sequence with run-time cursors executes ~150 scalar
+// instructions and a dozen branches per step, which is as long as the MFMA waves' step.)
+// MMSA_IGEMM3 = 0: never; 1: 32-wide results only; 2 (default): every eligible launch.  Read at every launch, so a test
+// can switch within one process.
 static int rows3_mode() {
   const char* e = getenv("MMSA_IGEMM3");
-  const int mode = e ? atoi(e) : 1;
-  return mode < 0 || mode > 2 ? 1 : mode;
+  const int mode = e ? atoi(e) : 2;
+  return mode < 0 || mode > 2 ? 2 : mode;
 }
 
 template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM, bool BNRELU>
@@ -453,6 +512,8 @@ static int launch_igemm3(const float* X, const ConvGeom& g, const Conv3Args& a, 
   for (int i = 0; i < a.n; ++i) bnrelu = bnrelu || a.bnrelu[i];
   if (g.Cout % 64 != 0) {
     if (stats || bnrelu) return MMSA_ERR_ARG;
+    for (int i = 0; i < a.n; ++i)
+      if (a.ntaps[i] != 9) return MMSA_ERR_ARG;   // the 128-row tile's ring of three strips cannot run single-tap groups
     if (accumulate) return launch_igemm3_inst<128, 32, 4, 1, false, true, false>(X, g, a, s);
     return launch_igemm3_inst<128, 32, 4, 1, false, false, false>(X, g, a, s);
   }

@@ -129,12 +129,19 @@ def test_gradients_for_a_spectrogram_of_another_length():
     sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     o64, g64, _ = model_ref.forward_backward(sd64, "audio", audio.double(), None, label)
     close(out["logits"], o64["logits"])
+    # With two utterances a single 2x2 max-pool near-tie that resolves differently moves a whole tensor's gradient by
+    # 1e-3 and more in ANY fp32 evaluation (the fp32 CPU oracle is 1.9e-3 from float64 in the stem's weight on this
+    # input, 2e-4 .. 5e-3 over other seeds; tests/probe_wide_grads.py prints both kernels and the CPU side by side), so
+    # the bar is: 1e-3, or three times the distance of the reference's own fp32 arithmetic from float64.
+    _, g32, _ = model_ref.forward_backward(sd, "audio", audio, None, label)
     for k, p in m.named_parameters():
         if is_noise_grad("audio", k):
             continue
         r = g64[k]
-        err = float(torch.linalg.vector_norm(p.grad.detach().cpu().double() - r) / (torch.linalg.vector_norm(r) + 1e-30))
-        assert err < 1e-3, f"{k}: relative L2 error {err:.3e}"
+        n = torch.linalg.vector_norm(r) + 1e-30
+        err = float(torch.linalg.vector_norm(p.grad.detach().cpu().double() - r) / n)
+        err32 = float(torch.linalg.vector_norm(g32[k].double() - r) / n)
+        assert err < max(1e-3, 3 * err32), f"{k}: relative L2 error {err:.3e} (fp32 CPU oracle: {err32:.3e})"
     wide = torch.randn(2, 1, 64, 680, generator=g).to(DEV)
     with pytest.raises(ValueError, match="too wide to train"):
         m(audio=wide, labels=label.to(DEV))

@@ -525,12 +525,11 @@ def test_split_k_dual_convolution_matches_the_unsplit_launch():
     assert torch.equal(outs[0], outs[1])
 
 
-def test_strip_sharing_kernel_on_every_eligible_launch(monkeypatch):
-    """The implicit GEMM that stages an input strip once per row of three taps runs by default only where it is faster
-    (32-channel results); MMSA_IGEMM3=2 hands it every 3x3 launch, so its statistics epilogue, multi-problem launch
-    (3x3 + centre tap, folded BatchNorm + ReLU), second operand pair, accumulate flag and split K range are checked
-    against the same float64 references as the general kernel.  Maps narrower than 11 columns stay with the general
-    kernel (a strip would need more gap rows than it has)."""
+def test_both_implicit_gemm_kernels_on_every_launch_shape(monkeypatch):
+    """Which kernel takes a 3x3 launch (MMSA_IGEMM3 = 0: the general implicit GEMM always; 1: the one that stages an
+    input strip once per row of three taps for 32-channel results only; 2, the default: for every 3x3 launch), and
+    both kernels against the same float64 references: statistics epilogue, multi-problem launch (3x3 + centre tap,
+    folded BatchNorm + ReLU), second operand pair, accumulate flag, split K range."""
     ops = _ops()
     from mmsa_amd import _lib
     dh, dw = [t[0] for t in ops.TAPS3X3], [t[1] for t in ops.TAPS3X3]
@@ -538,17 +537,17 @@ def test_strip_sharing_kernel_on_every_eligible_launch(monkeypatch):
     def shares(B, H, W, Cout):
         return _lib.query("mmsa_conv_shares_tap_rows", B, H, W, Cout, 9, ops._iarr(dh), ops._iarr(dw))
 
-    monkeypatch.delenv("MMSA_IGEMM3", raising=False)
+    monkeypatch.setenv("MMSA_IGEMM3", "1")
     assert shares(32, 32, 65, 32) == 1 and shares(32, 32, 65, 64) == 0
-    monkeypatch.setenv("MMSA_IGEMM3", "0")
+    monkeypatch.delenv("MMSA_IGEMM3", raising=False)
+    assert shares(32, 32, 65, 32) == 1 and shares(32, 32, 65, 64) == 1 and shares(32, 8, 16, 256) == 1
+    test_conv3x3_forward_and_stats(2, 5, 3, 32, 64)        # three columns: every tap row wraps within the tile
+    test_conv3x3_forward_and_stats(1, 1, 200, 32, 64)      # one image row: the rows above and below are all padding
+    test_conv3x3_forward_and_stats(2, 1, 1, 32, 64)        # a single pixel
+    monkeypatch.setenv("MMSA_IGEMM3", "0")                 # the general kernel on the same cases
     assert shares(32, 32, 65, 32) == 0
-    monkeypatch.setenv("MMSA_IGEMM3", "2")
-    assert shares(32, 32, 65, 64) == 1 and shares(32, 8, 16, 256) == 1
-    assert shares(2, 8, 10, 64) == 0 and shares(2, 8, 11, 64) == 1 and shares(2, 8, 21, 32) == 0
     for geom in GEOMS:
         test_conv3x3_forward_and_stats(*geom)
-    test_conv3x3_forward_and_stats(2, 5, 11, 32, 64)       # the narrowest map it takes: six gap rows per strip
-    test_conv3x3_forward_and_stats(1, 1, 200, 32, 64)      # one image row: the rows above and below are all padding
     for geom in [(3, 32, 65, 32, 64), (2, 16, 31, 64, 128), (40, 8, 16, 128, 256)]:
         test_paired_convolution_with_folded_batchnorm_relu(*geom)
     for geom in [(3, 32, 65, 32, 64), (2, 16, 32, 64, 128), (2, 8, 16, 128, 256)]:
