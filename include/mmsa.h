@@ -110,6 +110,14 @@ MMSA_API int mmsa_conv_tile_rows(int B, int H, int W, int Cout);
  * dh/dw are host arrays.  stats (optional): [2][Cout][B*tiles] per-tile column sums and sums of squares. */
 MMSA_API int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* stats, int B, int H, int W, int Cin,
                            int Cout, int ntaps, const int* dh_host, const int* dw_host, int accumulate, void* stream);
+/* mmsa_conv_fwd for the data gradient of a block's second convolution (autograd of multimodal_model.py:64-65): Y is
+ * the gradient with respect to relu(bn1(x)); the launch also leaves, in stats ([2][Cout][B*tiles], the layout above),
+ * the per-tile column sums of g = Y [bn1(x) > 0] and of g * xhat -- the two reductions of that BatchNorm's backward --
+ * so mmsa_bn_relu_bwd_finish needs no pass of its own over Y and x for them.  x [B,H,W,Cout]; coeff: bn1's [4][Cout]
+ * table.  3x3 offset tables with Cout % 64 == 0 only (mmsa_conv_shares_tap_rows tells): MMSA_ERR_ARG otherwise. */
+MMSA_API int mmsa_conv_fwd_bnrelu_bwd_stats(const float* X, const float* Wp, float* Y, float* stats, const float* x,
+                                            const float* coeff, int B, int H, int W, int Cin, int Cout, int ntaps,
+                                            const int* dh_host, const int* dw_host, void* stream);
 /* Y = conv(X, Wp) + X2 . Wp2 in one launch (X2 [B,H,W,Cin], Wp2 [Cout][Cin]): the data gradient of a residual block's
  * input, 3x3 branch plus 1x1 shortcut (autograd of multimodal_model.py:64-70) */
 MMSA_API int mmsa_conv_fwd_dual(const float* X, const float* Wp, const float* X2, const float* Wp2, float* Y, int B,
@@ -219,6 +227,11 @@ MMSA_API long mmsa_bn_relu_bwd_scratch_floats(long npos, int C);
 /* in place: gradient w.r.t. relu(BN(c1)) -> gradient w.r.t. c1; also dgamma, dbeta */
 MMSA_API int mmsa_bn_relu_bwd(float* dh, const float* c1, const float* coeff, float* dgamma, float* dbeta,
                               float* scratch, long npos, int C, int training, void* stream);
+/* the same with its two reductions already done (autograd of multimodal_model.py:64): partial [2][C][rows] holds the
+ * per-tile sums mmsa_conv_fwd_bnrelu_bwd_stats left behind; cb: 3 C floats of scratch */
+MMSA_API int mmsa_bn_relu_bwd_finish(float* dh, const float* c1, const float* coeff, const float* partial, int rows,
+                                     float* dgamma, float* dbeta, float* cb, long npos, int C, int training,
+                                     void* stream);
 
 /* ---- text branch: multimodal_model.py:149,179 (embedding gather, bit-exact), :186-197 (ReLU, max over time). */
 MMSA_API int mmsa_embedding_gather(const long long* ids, const float* table, float* out, long ntok, int E, long vocab,

@@ -1203,3 +1203,18 @@ MMSA_EXPORT int mmsa_bn_relu_bwd(float* dh, const float* c1, const float* coeff,
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dh, c1, coeff, cb, n4, C);
   return mmsa_launch_status();
 }
+
+// The same with the two reductions already done: partial [2][C][rows] holds per-tile sums of g = dh [bn(c1) > 0] and of
+// g * xhat (left behind by mmsa_conv_fwd_bnrelu_bwd_stats, the convolution that produced dh).  cb: 3 C floats of scratch.
+MMSA_EXPORT int mmsa_bn_relu_bwd_finish(float* dh, const float* c1, const float* coeff, const float* partial, int rows,
+                                        float* dgamma, float* dbeta, float* cb, long npos, int C, int training,
+                                        void* stream) {
+  MMSA_REQUIRE(dh && c1 && coeff && partial && dgamma && dbeta && cb && npos > 0 && rows > 0);
+  MMSA_REQUIRE(C >= 32 && C <= 256 && C % 32 == 0);
+  hipStream_t s = mmsa_stream(stream);
+  hipLaunchKernelGGL(bn_bwd_coeff_kernel, dim3(C), dim3(256), 0, s, partial, rows, (double)npos, coeff, dgamma, dbeta,
+                     (float*)nullptr, cb, C, training);
+  const long n4 = npos * (C / 4);
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, s, dh, c1, coeff, cb, n4, C);
+  return mmsa_launch_status();
+}

@@ -939,6 +939,27 @@ MMSA_EXPORT int mmsa_conv_fwd(const float* X, const float* Wp, float* Y, float* 
   return launch_igemm<64, 64, 2, 2>(X, Wp, Y, stats, g, accumulate, ConvMulti{}, s);
 }
 
+// mmsa_conv_fwd for a data gradient whose result Y is the gradient with respect to relu(bn(x)) (x [B,H,W,Cout], coeff
+// that BatchNorm's [4][Cout] table): also leaves in stats ([2][Cout][B*tiles], the layout of mmsa_conv_fwd's
+// statistics) the per-tile column sums of g = Y [bn(x) > 0] and of g * xhat, which mmsa_bn_relu_bwd_finish turns into
+// the BatchNorm's parameter gradients and the gradient with respect to x.  3x3 offset tables and Cout % 64 == 0 only
+// (mmsa_conv_shares_tap_rows tells): MMSA_ERR_ARG otherwise.
+MMSA_EXPORT int mmsa_conv_fwd_bnrelu_bwd_stats(const float* X, const float* Wp, float* Y, float* stats, const float* x,
+                                               const float* coeff, int B, int H, int W, int Cin, int Cout, int ntaps,
+                                               const int* dh, const int* dw, void* stream) {
+  MMSA_REQUIRE(X && Wp && Y && stats && x && coeff && dh && dw);
+  MMSA_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % KC == 0 && Cout % 64 == 0);
+  ConvGeom g;
+  if (fill_geom(g, B, H, W, Cin, Cout, ntaps, dh, dw) != MMSA_OK) return MMSA_ERR_ARG;
+  MMSA_REQUIRE(uses_rows3(B, H, W, Cout, ntaps, dh, dw));
+  Conv3Args a{};
+  a.n = 1;
+  a.ntaps[0] = 9; a.chunk0[0] = 0; a.chunk1[0] = Cin / KC;
+  a.Wp[0] = Wp; a.Y[0] = Y; a.stats[0] = stats; a.bsx[0] = x; a.bscoeff[0] = coeff;
+  a.second_z = -1;
+  return launch_igemm3(X, g, a, false, mmsa_stream(stream));
+}
+
 // Y[B,H,W,Cout] = conv(X, Wp) + X2 . Wp2 in one launch: X2 [B,H,W,Cin] is a second input with the same channel count
 // and Wp2 [Cout][Cin] its 1x1 weights (e.g. the data gradient of a residual block's input: the 3x3 branch plus the
 // 1x1 shortcut).

@@ -39,6 +39,8 @@ struct Conv3Args {
   const float* Wp[4];          // packed weights [ntaps][Cout][Cin]
   float* Y[4];
   float* stats[4];             // STATS instantiations
+  const float* bsx[4];         // STATS == 2: the map x [B,H,W,Cout] whose BatchNorm + ReLU the result is the gradient of,
+  const float* bscoeff[4];     // ... and that BatchNorm's coefficient table [4][Cout] (mean, 1/std, scale, shift)
   const float* bnrelu[4];      // BNRELU instantiations: [4][Cout] table or null
   const float* X2;             // optional second operand pair (see conv_igemm_kernel)
   const float* Wp2;
@@ -50,7 +52,11 @@ __device__ __forceinline__ void wait_vm_at_most() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STATS, bool ACCUM, bool BNRELU>
+// STATS: 0 none; 1 per-tile column sums and sums of squares of the result (BatchNorm batch statistics of a forward
+// convolution); 2 the result dY is the gradient with respect to relu(bn(x)): per-tile column sums of g = dY [bn(x) > 0]
+// and of g * xhat (the two reductions of the BatchNorm backward), so that the data-gradient convolution leaves them
+// behind and no separate pass over dY and x is needed for them.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STATS, bool ACCUM, bool BNRELU>
 __global__ __launch_bounds__(512) void conv_igemm3_kernel(const float* __restrict__ X, const ConvGeom g,
                                                           int tiles_per_img, const Conv3Args a) {
   static_assert(WAVES_M * WAVES_N == 4, "4 MFMA waves per workgroup (plus 4 loader waves)");
@@ -104,6 +110,7 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const float* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  float bx[TM][TN][16];   // STATS == 2: this lane's elements of x, requested before the K loop
   if (loader) {
     const float* Xb = X + (long)b * HW * g.Cin;
     const __amdgpu_buffer_rsrc_t rX =
@@ -326,6 +333,18 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const float* __restric
       }
     };
 
+    if (STATS == 2) {
+      const float* xb = a.bsx[z] + (long)b * HW * g.Cout;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int p = p0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            bx[i][j][r] = p < HW ? xb[(long)p * g.Cout + n0 + wn * WTN + j * 32 + li] : 0.f;
+          }
+    }
     Frag f0, f1;
     int slot = 0, bbuf = 0;
     // One step: the 16 MFMAs of tap position J on strip `slot` and weight tile `bbuf`; behind the first MFMA of each
@@ -397,16 +416,24 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const float* __restric
   const int li = lane & 31, lh = lane >> 5;
   float* Yb = Y + (long)b * HW * g.Cout;
   const float* __restrict__ ep = BNRELU ? a.bnrelu[z] : nullptr;   // uniform
-  float csum[TN], csq[TN], esc[TN], esh[TN];
+  float csum[TN], csq[TN], esc[TN], esh[TN], bmean[TN], bistd[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     csum[j] = csq[j] = 0.f;
     esc[j] = 1.f;
     esh[j] = 0.f;
+    bmean[j] = bistd[j] = 0.f;
+    const int col = n0 + wn * WTN + j * 32 + li;
     if (BNRELU && ep) {
-      const int col = n0 + wn * WTN + j * 32 + li;
       esc[j] = ep[2 * g.Cout + col];
       esh[j] = ep[3 * g.Cout + col];
+    }
+    if (STATS == 2) {
+      const float* bc = a.bscoeff[z];
+      bmean[j] = bc[col];
+      bistd[j] = bc[g.Cout + col];
+      esc[j] = bc[2 * g.Cout + col];
+      esh[j] = bc[3 * g.Cout + col];
     }
   }
 #pragma unroll
@@ -427,9 +454,15 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const float* __restric
           } else {
             *dst = v;
           }
-          if (STATS) {
+          if (STATS == 1) {
             csum[j] += raw;
             csq[j] = fmaf(raw, raw, csq[j]);
+          }
+          if (STATS == 2) {   // the expressions of bn_relu_bwd_stats_kernel
+            const float x = bx[i][j][r];
+            const float gr = fmaf(x, esc[j], esh[j]) > 0.f ? raw : 0.f;
+            csum[j] += gr;
+            csq[j] = fmaf(gr, (x - bmean[j]) * bistd[j], csq[j]);
           }
         }
       }
@@ -486,7 +519,7 @@ static int rows3_mode() {
   return mode < 0 || mode > 2 ? 2 : mode;
 }
 
-template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM, bool BNRELU>
+template <int BM, int BN, int WM_, int WN_, int STATS, bool ACCUM, bool BNRELU>
 int launch_igemm3_inst(const float* X, const ConvGeom& g, const Conv3Args& a, hipStream_t s) {
   constexpr size_t shmem = ((BM == 64 ? 4 : 3) * (size_t)(BM + 8) + 5 * (size_t)BN) * KC * sizeof(float);
   static bool attr_set = false;
@@ -510,21 +543,26 @@ static int launch_igemm3(const float* X, const ConvGeom& g, const Conv3Args& a, 
   const bool stats = a.stats[0] != nullptr;
   bool bnrelu = false;
   for (int i = 0; i < a.n; ++i) bnrelu = bnrelu || a.bnrelu[i];
+  const bool bwd_stats = a.bsx[0] != nullptr;
+  if (bwd_stats) {
+    if (!stats || bnrelu || accumulate || g.Cout % 64 != 0 || a.n != 1 || !a.bscoeff[0]) return MMSA_ERR_ARG;
+    return launch_igemm3_inst<64, 64, 2, 2, 2, false, false>(X, g, a, s);
+  }
   if (g.Cout % 64 != 0) {
     if (stats || bnrelu) return MMSA_ERR_ARG;
     for (int i = 0; i < a.n; ++i)
       if (a.ntaps[i] != 9) return MMSA_ERR_ARG;   // the 128-row tile's ring of three strips cannot run single-tap groups
-    if (accumulate) return launch_igemm3_inst<128, 32, 4, 1, false, true, false>(X, g, a, s);
-    return launch_igemm3_inst<128, 32, 4, 1, false, false, false>(X, g, a, s);
+    if (accumulate) return launch_igemm3_inst<128, 32, 4, 1, 0, true, false>(X, g, a, s);
+    return launch_igemm3_inst<128, 32, 4, 1, 0, false, false>(X, g, a, s);
   }
   if (bnrelu) {
     if (stats || accumulate) return MMSA_ERR_ARG;
-    return launch_igemm3_inst<64, 64, 2, 2, false, false, true>(X, g, a, s);
+    return launch_igemm3_inst<64, 64, 2, 2, 0, false, true>(X, g, a, s);
   }
   if (stats) {
     if (accumulate) return MMSA_ERR_ARG;
-    return launch_igemm3_inst<64, 64, 2, 2, true, false, false>(X, g, a, s);
+    return launch_igemm3_inst<64, 64, 2, 2, 1, false, false>(X, g, a, s);
   }
-  if (accumulate) return launch_igemm3_inst<64, 64, 2, 2, false, true, false>(X, g, a, s);
-  return launch_igemm3_inst<64, 64, 2, 2, false, false, false>(X, g, a, s);
+  if (accumulate) return launch_igemm3_inst<64, 64, 2, 2, 0, true, false>(X, g, a, s);
+  return launch_igemm3_inst<64, 64, 2, 2, 0, false, false>(X, g, a, s);
 }

@@ -20,6 +20,9 @@ _SIDE_STREAMS = {}
 import os as _os
 FORK_WGRAD = _os.environ.get("MMSA_FORK_WGRAD", "1") != "0"
 FORK_ANY = _os.environ.get("MMSA_FORK", "1") != "0"     # 0: the whole step on one stream (diagnostics)
+# 0: BatchNorm-backward reductions of a block's first BatchNorm by a pass of their own instead of in the epilogue of
+# the data-gradient convolution that produces their input (A/B aid)
+FUSE_BN_BWD_STATS = _os.environ.get("MMSA_FUSE_BN_BWD_STATS", "1") != "0"
 # 1: a block's first 3x3 convolution and its 1x1 shortcut share one launch (and one BatchNorm coefficient launch)
 FWD_PAIR = _os.environ.get("MMSA_FWD_PAIR", "1") != "0"
 # 1: inference folds bn1 + ReLU into the epilogue of a block's first convolution (0: separate pass, as in training)
@@ -257,7 +260,16 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
 
     ops.stamp(name + ".main.dc2_ready")
     f2 = fork(ws, d_out.device, enable=FORK_WGRAD).mark()           # d_c2 / d_sc are ready
-    ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
+    # the data gradient of conv2 is the gradient with respect to relu(bn1(c1)): where the strip-sharing kernel runs, its
+    # epilogue leaves the two reductions of bn1's backward behind and the separate pass over d_h1 and c1 is not needed
+    fused_stats = FUSE_BN_BWD_STATS and ops.conv_shares_tap_rows(B, H, W, Cout, ops.TAPS3X3, negate=True)
+    if fused_stats:
+        rows, _ = ops.conv_stats_rows(B, H, W, Cout)
+        part = ws.buf(name + ".bnrelu_partial", rows * 2 * Cout)
+        ops.conv_fwd_bnrelu_bwd_stats(d_c2, s.w2d, d_h1, part, s.c1, s.coeff1, B, H, W, Cout, Cout, ops.TAPS3X3,
+                                      negate=True)
+    else:
+        ops.conv_fwd(d_c2, s.w2d, d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
     if deferred is not None:
         deferred.append(wgrad_conv2)
     else:
@@ -265,9 +277,13 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
             ops.stamp(name + ".side.wgrad2_start")
             wgrad_conv2()
             ops.stamp(name + ".side.wgrad2_end")
-    sc2 = ws.buf(name + ".bnrelu_scratch", ops.bn_relu_bwd_scratch(B * H * W, Cout))
-    ops.bn_relu_bwd(d_h1, s.c1, s.coeff1, grads.of(blk.bn1.weight), grads.of(blk.bn1.bias), sc2, B * H * W, Cout,
-                    training)
+    if fused_stats:
+        ops.bn_relu_bwd_finish(d_h1, s.c1, s.coeff1, part, rows, grads.of(blk.bn1.weight), grads.of(blk.bn1.bias),
+                               ws.buf(name + ".bnrelu_cb", 3 * Cout), B * H * W, Cout, training)
+    else:
+        sc2 = ws.buf(name + ".bnrelu_scratch", ops.bn_relu_bwd_scratch(B * H * W, Cout))
+        ops.bn_relu_bwd(d_h1, s.c1, s.coeff1, grads.of(blk.bn1.weight), grads.of(blk.bn1.bias), sc2, B * H * W, Cout,
+                        training)
     ops.stamp(name + ".main.dc1_ready")
     f1 = fork(ws, d_out.device, enable=FORK_WGRAD).mark()           # d_c1 is ready
     if need_dx:

@@ -49,7 +49,7 @@ def _igemm_name(bm, bn, stats, accum, geom, kchunks, nproblems=1, bnrelu=False, 
     wm, wn = (4, 1) if bn == 32 else (2, 2)
     if offsets is not None and _lib.query("mmsa_conv_shares_tap_rows", *geom, len(offsets), _iarr([o[0] for o in offsets]),
                                           _iarr([o[1] for o in offsets])):
-        return "conv_igemm3_kernel<%d,%d,%d,%d,%s,%s,%s>" % (bm, bn, wm, wn, "true" if stats else "false",
+        return "conv_igemm3_kernel<%d,%d,%d,%d,%d,%s,%s>" % (bm, bn, wm, wn, 1 if stats else 0,
                                                               "true" if accum else "false",
                                                               "true" if bnrelu else "false")
     ring = _lib.query("mmsa_conv_ring_buffers", *geom, nproblems, kchunks)
@@ -618,6 +618,38 @@ def bn_relu_bwd(dh, c1, coeff, dgamma, dbeta, scratch, npos, C, training):
         raise ValueError("bn_relu_bwd: bad sizes")
     _lib.call("mmsa_bn_relu_bwd", _chk(dh), _chk(c1), _chk(coeff), _chk(dgamma), _chk(dbeta), _chk(scratch), npos, C,
               int(training), _stream())
+
+
+def conv_shares_tap_rows(B, H, W, Cout, taps, negate=False) -> bool:
+    """Whether a convolution with this offset table runs on the kernel that stages an input strip once per tap row."""
+    sgn = -1 if negate else 1
+    return bool(_lib.query("mmsa_conv_shares_tap_rows", B, H, W, Cout, len(taps), _iarr([sgn * t[0] for t in taps]),
+                           _iarr([sgn * t[1] for t in taps])))
+
+
+def conv_fwd_bnrelu_bwd_stats(X, Wp, Y, stats, x, coeff, B, H, W, Cin, Cout, taps, negate=False):
+    """:func:`conv_fwd` for a data gradient Y = d loss / d relu(bn(x)): the launch also leaves the per-tile sums of
+    g = Y [bn(x) > 0] and g * xhat in ``stats`` ([2][Cout][rows], rows as :func:`conv_stats_rows`)."""
+    rows, _ = conv_stats_rows(B, H, W, Cout)
+    if (X.numel() != B * H * W * Cin or Y.numel() != B * H * W * Cout or Wp.numel() != len(taps) * Cin * Cout
+            or x.numel() != Y.numel() or coeff.numel() != 4 * Cout or stats.numel() != rows * 2 * Cout):
+        raise ValueError("conv_fwd_bnrelu_bwd_stats: operand sizes do not match the geometry")
+    sgn = -1 if negate else 1
+    ev = None
+    if PROFILE is not None:
+        ev = _prof_begin("conv_igemm3_kernel<64,64,2,2,2,false,false>", 2.0 * B * H * W * Cin * Cout * len(taps))
+    _lib.call("mmsa_conv_fwd_bnrelu_bwd_stats", _chk(X), _chk(Wp), _chk(Y), _chk(stats), _chk(x), _chk(coeff), B, H, W,
+              Cin, Cout, len(taps), _iarr([sgn * t[0] for t in taps]), _iarr([sgn * t[1] for t in taps]), _stream())
+    if ev is not None:
+        ev.record()
+    return rows
+
+
+def bn_relu_bwd_finish(dh, c1, coeff, partial, rows, dgamma, dbeta, cb, npos, C, training):
+    if dh.numel() != npos * C or c1.numel() != npos * C or partial.numel() != rows * 2 * C or cb.numel() < 3 * C:
+        raise ValueError("bn_relu_bwd_finish: bad sizes")
+    _lib.call("mmsa_bn_relu_bwd_finish", _chk(dh), _chk(c1), _chk(coeff), _chk(partial), rows, _chk(dgamma), _chk(dbeta),
+              _chk(cb), npos, C, int(training), _stream())
 
 
 # ---------------------------------------------------------------------------------------------- text branch

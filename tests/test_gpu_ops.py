@@ -525,6 +525,53 @@ def test_split_k_dual_convolution_matches_the_unsplit_launch():
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("B,H,W,C", [(3, 32, 65, 64), (2, 16, 32, 128), (5, 8, 16, 256), (2, 7, 19, 64)])
+def test_data_gradient_with_batchnorm_backward_sums_in_its_epilogue(B, H, W, C):
+    """The data gradient of a block's second convolution with the two reductions of bn1's backward formed in its
+    epilogue, then mmsa_bn_relu_bwd_finish, against the same convolution followed by mmsa_bn_relu_bwd (which makes a
+    pass of its own over the gradient and c1 for the sums), and against float64 autograd of relu(bn(c1)) -> conv."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3 + C)
+    c1 = torch.randn(B, C, H, W, generator=g)
+    w2 = torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5
+    d_c2 = torch.randn(B, C, H, W, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    # float64 reference: c1 -> BatchNorm (batch statistics) -> ReLU -> conv2, gradient d_c2 at the output
+    x = c1.double().requires_grad_(True)
+    ga, be = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    h = F.relu(F.batch_norm(x, None, None, ga, be, True, 0.1, 1e-5))
+    F.conv2d(h, w2.double(), None, 1, 1).backward(d_c2.double())
+    # the BatchNorm coefficient table [4][C]: mean, 1/std, scale, shift
+    mean = c1.double().mean((0, 2, 3))
+    var = c1.double().var((0, 2, 3), unbiased=False)
+    istd = 1.0 / torch.sqrt(var + 1e-5)
+    coeff = torch.stack([mean, istd, gamma.double() * istd, beta.double() - mean * gamma.double() * istd]).float().to(DEV)
+    wd = torch.empty(w2.numel(), device=DEV)
+    ops.pack_weights(w2.to(DEV), None, wd)
+    c1d, dyd = nhwc(c1).to(DEV), nhwc(d_c2).to(DEV)
+    npos = B * H * W
+    outs = []
+    for fused in (False, True):
+        dh = torch.empty(B, H, W, C, device=DEV)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        if fused:
+            rows, _ = ops.conv_stats_rows(B, H, W, C)
+            part = torch.zeros(2 * C * rows, device=DEV)
+            ops.conv_fwd_bnrelu_bwd_stats(dyd, wd, dh, part, c1d, coeff.flatten(), B, H, W, C, C, ops.TAPS3X3, negate=True)
+            ops.bn_relu_bwd_finish(dh, c1d, coeff.flatten(), part, rows, dg, db, torch.empty(3 * C, device=DEV), npos, C,
+                                   True)
+        else:
+            ops.conv_fwd(dyd, wd, dh, None, B, H, W, C, C, ops.TAPS3X3, negate=True)
+            ops.bn_relu_bwd(dh, c1d, coeff.flatten(), dg, db, torch.empty(ops.bn_relu_bwd_scratch(npos, C), device=DEV),
+                            npos, C, True)
+        outs.append((dh, dg, db))
+        check(nchw(dh.cpu()), x.grad, 2e-5)
+        check(dg.cpu(), ga.grad, 2e-5)
+        check(db.cpu(), be.grad, 2e-5)
+    for a, b in zip(*outs):
+        check(a, b, 2e-6)
+
+
 def test_both_implicit_gemm_kernels_on_every_launch_shape(monkeypatch):
     """Which kernel takes a 3x3 launch (MMSA_IGEMM3 = 0: the general implicit GEMM always; 1: the one that stages an
     input strip once per row of three taps for 32-channel results only; 2, the default: for every 3x3 launch), and
