@@ -164,7 +164,7 @@ def _conv_pair_bn(ws, name, X, w1f, wsf, bn1, bns, B, H, W, Cin, Cout, training,
     return Y1, c1, Ys, cs
 
 
-def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: Workspace, packs):
+def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: Workspace, packs, hook=None):
     """One ResidualBlock + the 2x2 max-pool that follows it.  a_in: [B,H,W,Cin] -> [B,H/2,W/2,Cout]."""
     s = SimpleNamespace(B=B, H=H, W=W, Cin=Cin, Cout=Cout, a_in=a_in, name=name)
     s.w1f, s.w1d = packs[name + ".c1"]
@@ -186,6 +186,8 @@ def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: 
                                          ops.TAPS1X1, training, False)
         s.c1, s.coeff1, _ = _conv_bn(ws, name + ".c1", a_in, s.w1f, blk.bn1, B, H, W, Cin, Cout, ops.TAPS3X3,
                                      training, False)
+    if hook is not None:
+        hook()          # the caller's side work, enqueued behind this block's first convolution
     if not fold:
         s.h1 = ws.buf(name + ".h1", (B, H, W, Cout))
         ops.bn_relu_apply(s.c1, s.coeff1, s.h1, B * H * W, Cout)
@@ -303,8 +305,12 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
     return d_in
 
 
-def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Workspace):
-    """x: [B,1,H,W] (or [B,H,W]) float32 on the GPU -> (features [B,256], saved state)."""
+def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Workspace, side_work=None):
+    """x: [B,1,H,W] (or [B,H,W]) float32 on the GPU -> (features [B,256], saved state).
+    side_work: optional (k, fn): fn() is called once block k's kernels (k = 1..3; 0: the stem's) have been enqueued --
+    the caller's independent work (the text branch), which forks its own helper stream there.  fn may return a second
+    callable, which is then called behind the first convolution of the following block (so that the critical-path
+    kernel is enqueued ahead of the side work that starts at the same point)."""
     if x.dim() == 4:
         if x.shape[1] != 1:
             raise ValueError("audio input must have one channel")
@@ -346,12 +352,20 @@ def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Works
                 hh, ww, cc = hh // 2, ww // 2, cc * 2
     fpack.join()
     ops.stamp("fwd.stem_done")
+    pending = None
+    if side_work is not None and side_work[0] == 0:
+        pending = side_work[1]()
     for i, blk in enumerate((m.res_block1, m.res_block2, m.res_block3)):
         cout = blk.conv1.weight.shape[0]
-        s = block_forward(blk, f"rb{i + 1}", a, B, h, w, cin, cout, training, need_grad, ws, packs)
+        s = block_forward(blk, f"rb{i + 1}", a, B, h, w, cin, cout, training, need_grad, ws, packs, hook=pending)
+        pending = None
         st.blocks.append(s)
         a, h, w, cin = s.out, h // 2, w // 2, cout
         ops.stamp(f"fwd.rb{i + 1}_done")
+        if side_work is not None and side_work[0] == i + 1:
+            pending = side_work[1]()
+    if pending is not None:
+        pending()
     st.P, st.C = h * w, cin
     feat = ws.buf("audio.feat", (B, cin))
     ops.gap_fwd(a, feat, B, st.P, cin)

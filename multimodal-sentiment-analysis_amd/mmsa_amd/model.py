@@ -15,6 +15,8 @@ Training support comes in two forms:
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional
 
 import torch
@@ -417,6 +419,13 @@ class _ModelFn(torch.autograd.Function):
         return none + tuple(views)
 
 
+# where the text branch's helper stream forks off the audio branch: -1 ahead of the stem (default), 0 behind the stem,
+# k = 1..3 behind residual block k (A/B aid)
+_TEXT_FORK_AT = int(os.environ.get("MMSA_TEXT_FORK_AT", "0"))
+# 1: the fork point is fixed there, but the text branch's kernels are enqueued behind the next block's first convolution
+_TEXT_FORK_MARK = os.environ.get("MMSA_TEXT_FORK_MARK", "0") == "1"
+
+
 class MultimodalSentimentModel(nn.Module):
     def __init__(self, modality="both", num_classes=3, audio_dropout=0.5, text_dropout=0.3, fusion_dropout=0.5,
                  vocab_size=30522, embedding_dim=256, filter_sizes=[3, 4, 5], num_filters=128, max_length=128):
@@ -503,11 +512,28 @@ class MultimodalSentimentModel(nn.Module):
         if self.modality == "both":
             # the two branches are independent until the head: the (small) text branch runs on a helper stream; it is
             # enqueued first so that it starts beside the stem instead of colliding with the last block's convolutions
-            with audio_engine.fork(ws, arena.device, 1) as f:
-                t_feat, run.text = text_engine.text_forward(self.text_model, input_ids, need_grad, ws)
+            where = _TEXT_FORK_AT
+            box = {}
+
+            def text_branch():
+                fk = audio_engine.fork(ws, arena.device, 1)
+                box["fork"] = fk
+
+                def body():
+                    with fk:
+                        box["out"] = text_engine.text_forward(self.text_model, input_ids, need_grad, ws)
+                if _TEXT_FORK_MARK and where >= 0:
+                    fk.mark()
+                    return body
+                body()
+                return None
+            if where < 0:
+                text_branch()
             a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, self.audio_model.training,
-                                                           need_grad, ws)
-            f.join()
+                                                           need_grad, ws, side_work=(where, text_branch) if where >= 0
+                                                           else None)
+            t_feat, run.text = box["out"]
+            box["fork"].join()
         elif self.modality == "audio":
             a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, self.audio_model.training,
                                                            need_grad, ws)
