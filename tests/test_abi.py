@@ -245,7 +245,7 @@ def test_bench_reads_the_committed_rocprof_summary():
         "conv_igemm_kernel<64,64,2,2,true,false,5>"
     rows, src = bench.rocprof_summary()
     assert src and src.startswith("profiles/r") and src.endswith("_kernel_stats.csv")
-    matrix = [k for k in rows if k.startswith(("conv_igemm_kernel<", "conv_wgrad2_kernel<"))]
+    matrix = [k for k in rows if k.startswith(("conv_igemm_kernel<", "conv_igemm3_kernel<", "conv_wgrad2_kernel<"))]
     assert len(matrix) >= 8
     top = max(matrix, key=lambda k: rows[k][1])
     avg_us, total_us, calls = rows[top]
