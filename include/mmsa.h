@@ -205,6 +205,10 @@ MMSA_API int mmsa_se_gate(const float* bsum, const float* coeff, const float* W1
 /* out[B,H/2,W/2,C] = maxpool2( relu( BN2(c2) * gate + BN_s(sc) ) ) */
 MMSA_API int mmsa_res_gate_relu_pool(const float* c2, const float* sc, const float* coeff2, const float* coeffs,
                                      const float* gate, float* out, int B, int H, int W, int C, void* stream);
+/* the same for the last block of the audio branch, whose pooled output only feeds AdaptiveAvgPool2d(1)
+ * (multimodal_model.py:123-125): feat[B][C] = mean over the pooled positions, no pooled map is stored */
+MMSA_API int mmsa_res_gate_relu_pool_mean(const float* c2, const float* sc, const float* coeff2, const float* coeffs,
+                                          const float* gate, float* feat, int B, int H, int W, int C, void* stream);
 /* the block tail without the pooling, every part optional: out = [relu]((a*scale2+shift2)*gate + (sc*scale_s+shift_s));
  * null coefficient table = identity, null gate = 1, null sc = 0: SEBlock.forward alone (multimodal_model.py:38-42:
  * x * gate) and ResidualBlock.forward alone (:64-70, identity or projection shortcut) */
@@ -219,6 +223,14 @@ MMSA_API int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const floa
                                   const float* bsum, const float* W1, const float* W2, float* d_c2, float* d_sc,
                                   float* dgamma2, float* dbeta2, float* dgammas, float* dbetas, float* dW1, float* dW2,
                                   float* scratch, int B, int H, int W, int C, int training, void* stream);
+/* mmsa_resblock_bwd_ew for that last block: dfeat [B][C] is the gradient with respect to the pooled mean (autograd of
+ * multimodal_model.py:123-125), no gradient map of the pooled output is formed */
+MMSA_API int mmsa_resblock_bwd_ew_from_mean(const float* dfeat, const float* c2, const float* sc, const float* coeff2,
+                                            const float* coeffs, const float* gate, const float* hid,
+                                            const float* gap, const float* bsum, const float* W1, const float* W2,
+                                            float* d_c2, float* d_sc, float* dgamma2, float* dbeta2, float* dgammas,
+                                            float* dbetas, float* dW1, float* dW2, float* scratch, int B, int H, int W,
+                                            int C, int training, void* stream);
 /* dW1, dW2 may both be null in mmsa_resblock_bwd_ew: the squeeze-excite weight gradients are then left to this call
  * (same scratch and geometry), which can run on another stream since nothing but the optimiser reads them */
 MMSA_API int mmsa_resblock_bwd_se_wgrad(const float* scratch, const float* hid, const float* gap, float* dW1,

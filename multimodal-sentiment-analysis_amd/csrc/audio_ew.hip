@@ -532,6 +532,41 @@ __global__ void res_gate_relu_pool_kernel(const float* __restrict__ c2, const fl
   }
 }
 
+// The last block of the audio branch: the same pooled values, but only their mean over the pooled positions is wanted
+// (AdaptiveAvgPool2d(1) follows, multimodal_model.py:123-125).  grid = (C / 64, B): lane = channel, the four waves take
+// every fourth pooled position, their sums are added in wave order.
+__global__ __launch_bounds__(256) void res_gate_relu_pool_mean_kernel(const float* __restrict__ c2,
+                                                                      const float* __restrict__ sc,
+                                                                      const float* __restrict__ coeff2,
+                                                                      const float* __restrict__ coeffs,
+                                                                      const float* __restrict__ gate,
+                                                                      float* __restrict__ feat, int H, int W, int C) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
+  const int H2 = H / 2, W2 = W / 2, P2 = H2 * W2;
+  const float s2 = coeff2[2 * C + c], h2c = coeff2[3 * C + c], ss = coeffs[2 * C + c], hs = coeffs[3 * C + c];
+  const float gt = gate[(long)b * C + c];
+  float acc = 0.f;
+  for (int p2 = w; p2 < P2; p2 += 4) {
+    const int h2 = p2 / W2, w2 = p2 - h2 * W2;
+    float a[4], s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long off = (((long)b * H + 2 * h2 + (k >> 1)) * W + 2 * w2 + (k & 1)) * C + c;
+      a[k] = c2[off];
+      s[k] = sc[off];
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = fmaxf(m, fmaf(fmaf(a[k], s2, h2c), gt, fmaf(s[k], ss, hs)));
+    acc += m;
+  }
+  part[w][lane] = acc;
+  __syncthreads();
+  if (w == 0) feat[(long)b * C + c] = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) / (float)P2;
+}
+
 // The same arithmetic without the pooling, every part optional: out = [relu]( (a * s2 + h2) * gate + (s * ss + hs) ),
 // a null coefficient table meaning scale 1 / shift 0, a null gate 1, a null second map 0.  Serves the stand-alone
 // SEBlock (x * gate) and ResidualBlock (no pool; identity or projection shortcut) forwards.
@@ -610,7 +645,7 @@ __global__ __launch_bounds__(256) void res_pool_bwd_kernel(const float* __restri
                                                            const float* __restrict__ coeffs,
                                                            const float* __restrict__ gate, float* __restrict__ dz,
                                                            float* __restrict__ partial, int H, int W, int C, int chunk,
-                                                           int nchunks) {
+                                                           int nchunks, int dout_mean) {
   extern __shared__ float red[];  // [planes][3][C]
   const int c4n = C >> 2, planes = 256 / c4n;
   const int q = threadIdx.x % c4n, pl = threadIdx.x / c4n;
@@ -626,7 +661,14 @@ __global__ __launch_bounds__(256) void res_pool_bwd_kernel(const float* __restri
   const int pend = min((ch + 1) * chunk, P2);
   for (int p2 = ch * chunk + pl; p2 < pend; p2 += planes) {
     const int h2 = p2 / W2, w2 = p2 - h2 * W2;
-    const f32x4 d = *reinterpret_cast<const f32x4*>(dout + ((long)b * P2 + p2) * C + c);
+    // dout_mean: dout is [B][C], the gradient with respect to the mean over the pooled positions (global average pool
+    // behind the last block): every position's gradient is that value / P2
+    f32x4 d = *reinterpret_cast<const f32x4*>(dout + (dout_mean ? (long)b * C : ((long)b * P2 + p2) * C) + c);
+    if (dout_mean) {
+      const float inv = 1.0f / (float)P2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] *= inv;
+    }
     f32x4 av[4], sv[4];
     long offs[4];
 #pragma unroll
@@ -1075,6 +1117,16 @@ MMSA_EXPORT int mmsa_res_gate_relu_pool(const float* c2, const float* sc, const 
 
 // out[B][P][C] = [relu]( (a * scale2 + shift2) * gate[b][c] + (sc * scale_s + shift_s) ); coeff2 / coeffs are
 // [4][C] BatchNorm coefficient tables (rows 2, 3 = scale, shift) or null (identity), gate [B][C] or null (1), sc null (0).
+// feat[B][C] = mean over the pooled positions of what mmsa_res_gate_relu_pool would store (C a multiple of 64)
+MMSA_EXPORT int mmsa_res_gate_relu_pool_mean(const float* c2, const float* sc, const float* coeff2, const float* coeffs,
+                                             const float* gate, float* feat, int B, int H, int W, int C, void* stream) {
+  MMSA_REQUIRE(c2 && sc && coeff2 && coeffs && gate && feat && B > 0 && B <= 65535 && H >= 2 && W >= 2);
+  MMSA_REQUIRE(C >= 64 && C % 64 == 0);
+  hipLaunchKernelGGL(res_gate_relu_pool_mean_kernel, dim3(C / 64, B), dim3(256), 0, mmsa_stream(stream), c2, sc, coeff2,
+                     coeffs, gate, feat, H, W, C);
+  return mmsa_launch_status();
+}
+
 MMSA_EXPORT int mmsa_gate_affine_add(const float* a, const float* coeff2, const float* gate, const float* sc,
                                      const float* coeffs, float* out, int B, int P, int C, int relu, void* stream) {
   MMSA_REQUIRE(a && out && B > 0 && P > 0 && C > 0 && C % 4 == 0 && (sc || !coeffs));
@@ -1113,12 +1165,11 @@ MMSA_EXPORT long mmsa_resblock_bwd_scratch_floats(int B, int H, int W, int C) {
 // Elementwise part of a residual block's backward (everything between the pooled output gradient and the
 // two convolution gradients):  dout[B,H/2,W/2,C] -> d_c2[B,H,W,C], d_sc[B,H,W,C] plus the gradients of
 // bn2 / shortcut-BN affine parameters and of the two squeeze-excite matrices.
-MMSA_EXPORT int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const float* sc, const float* coeff2,
-                                     const float* coeffs, const float* gate, const float* hid, const float* gap,
-                                     const float* bsum, const float* W1, const float* W2, float* d_c2, float* d_sc,
-                                     float* dgamma2, float* dbeta2, float* dgammas, float* dbetas, float* dW1,
-                                     float* dW2, float* scratch, int B, int H, int W, int C, int training,
-                                     void* stream) {
+static int resblock_bwd_ew_impl(const float* dout, int dout_mean, const float* c2, const float* sc, const float* coeff2,
+                                const float* coeffs, const float* gate, const float* hid, const float* gap,
+                                const float* bsum, const float* W1, const float* W2, float* d_c2, float* d_sc,
+                                float* dgamma2, float* dbeta2, float* dgammas, float* dbetas, float* dW1, float* dW2,
+                                float* scratch, int B, int H, int W, int C, int training, void* stream) {
   MMSA_REQUIRE(dout && c2 && sc && coeff2 && coeffs && gate && hid && gap && bsum && W1 && W2 && d_c2 && d_sc);
   MMSA_REQUIRE(dgamma2 && dbeta2 && dgammas && dbetas && scratch && (dW1 != nullptr) == (dW2 != nullptr));
   MMSA_REQUIRE(B > 0 && H >= 2 && W >= 2 && C >= 64 && C <= 256 && C % 64 == 0);
@@ -1135,7 +1186,7 @@ MMSA_EXPORT int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const f
   float* tab = dg + (long)B * C;
   float* dz = d_sc;  // pass A writes dz where d_sc will end up; pass B converts it in place
   hipLaunchKernelGGL(res_pool_bwd_kernel, dim3(B * nchunks), dim3(256), (size_t)planes * 3 * C * sizeof(float), s, dout,
-                     c2, sc, coeff2, coeffs, gate, dz, partial, H, W, C, chunk, nchunks);
+                     c2, sc, coeff2, coeffs, gate, dz, partial, H, W, C, chunk, nchunks, dout_mean);
   hipLaunchKernelGGL(se_bwd_kernel, dim3(B), dim3(256), 0, s, partial, nchunks, coeff2, gate, hid, W1, W2, A, du, dhp,
                      dg, C, Ch);
   hipLaunchKernelGGL(rb_bwd_coeff_kernel, dim3(mmsa_cdiv(C, 16)), dim3(256), 0, s, A, gate, dg, bsum, coeff2, coeffs, B,
@@ -1149,6 +1200,28 @@ MMSA_EXPORT int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const f
   hipLaunchKernelGGL(rb_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, s, dz, c2, sc, tab, d_c2, d_sc, B,
                      (long)H * W, C);
   return mmsa_launch_status();
+}
+
+MMSA_EXPORT int mmsa_resblock_bwd_ew(const float* dout, const float* c2, const float* sc, const float* coeff2,
+                                     const float* coeffs, const float* gate, const float* hid, const float* gap,
+                                     const float* bsum, const float* W1, const float* W2, float* d_c2, float* d_sc,
+                                     float* dgamma2, float* dbeta2, float* dgammas, float* dbetas, float* dW1,
+                                     float* dW2, float* scratch, int B, int H, int W, int C, int training,
+                                     void* stream) {
+  return resblock_bwd_ew_impl(dout, 0, c2, sc, coeff2, coeffs, gate, hid, gap, bsum, W1, W2, d_c2, d_sc, dgamma2, dbeta2,
+                              dgammas, dbetas, dW1, dW2, scratch, B, H, W, C, training, stream);
+}
+
+// The same for the last block of the audio branch, whose pooled output only feeds the global average pool: dfeat is
+// [B][C], the gradient with respect to that average (no [B][H/2][W/2][C] gradient map is formed).
+MMSA_EXPORT int mmsa_resblock_bwd_ew_from_mean(const float* dfeat, const float* c2, const float* sc, const float* coeff2,
+                                               const float* coeffs, const float* gate, const float* hid,
+                                               const float* gap, const float* bsum, const float* W1, const float* W2,
+                                               float* d_c2, float* d_sc, float* dgamma2, float* dbeta2, float* dgammas,
+                                               float* dbetas, float* dW1, float* dW2, float* scratch, int B, int H,
+                                               int W, int C, int training, void* stream) {
+  return resblock_bwd_ew_impl(dfeat, 1, c2, sc, coeff2, coeffs, gate, hid, gap, bsum, W1, W2, d_c2, d_sc, dgamma2,
+                              dbeta2, dgammas, dbetas, dW1, dW2, scratch, B, H, W, C, training, stream);
 }
 
 // Gradients of the two squeeze-excite matrices from the scratch mmsa_resblock_bwd_ew left behind (same geometry,

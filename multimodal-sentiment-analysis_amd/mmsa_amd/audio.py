@@ -23,6 +23,9 @@ FORK_ANY = _os.environ.get("MMSA_FORK", "1") != "0"     # 0: the whole step on o
 # 0: BatchNorm-backward reductions of a block's first BatchNorm by a pass of their own instead of in the epilogue of
 # the data-gradient convolution that produces their input (A/B aid)
 FUSE_BN_BWD_STATS = _os.environ.get("MMSA_FUSE_BN_BWD_STATS", "1") != "0"
+# 0: the global average pool behind the last block (and its backward) as launches of their own instead of inside the
+# block's pooling kernel / its backward (A/B aid)
+FUSE_GAP = _os.environ.get("MMSA_FUSE_GAP", "1") != "0"
 # 1: a block's first 3x3 convolution and its 1x1 shortcut share one launch (and one BatchNorm coefficient launch)
 FWD_PAIR = _os.environ.get("MMSA_FWD_PAIR", "1") != "0"
 # 1: inference folds bn1 + ReLU into the epilogue of a block's first convolution (0: separate pass, as in training)
@@ -164,7 +167,8 @@ def _conv_pair_bn(ws, name, X, w1f, wsf, bn1, bns, B, H, W, Cin, Cout, training,
     return Y1, c1, Ys, cs
 
 
-def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: Workspace, packs, hook=None):
+def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: Workspace, packs, hook=None,
+                  mean_out=None):
     """One ResidualBlock + the 2x2 max-pool that follows it.  a_in: [B,H,W,Cin] -> [B,H/2,W/2,Cout]."""
     s = SimpleNamespace(B=B, H=H, W=W, Cin=Cin, Cout=Cout, a_in=a_in, name=name)
     s.w1f, s.w1d = packs[name + ".c1"]
@@ -199,15 +203,20 @@ def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: 
     s.hid = ws.buf(name + ".hid", (B, Ch))
     s.gate = ws.buf(name + ".gate", (B, Cout))
     ops.se_gate(s.bsum2, s.coeff2, W1, W2, H * W, s.gap, s.hid, s.gate, B, Cout)
-    s.out = ws.buf(name + ".out", (B, H // 2, W // 2, Cout))
     if fsc is not None:
         fsc.join()
+    if mean_out is not None:
+        # the branch's last block: only the mean of its pooled output is wanted (the global average pool follows)
+        s.out = None
+        ops.res_gate_relu_pool_mean(s.c2, s.sc, s.coeff2, s.coeffs, s.gate, mean_out, B, H, W, Cout)
+        return s
+    s.out = ws.buf(name + ".out", (B, H // 2, W // 2, Cout))
     ops.res_gate_relu_pool(s.c2, s.sc, s.coeff2, s.coeffs, s.gate, s.out, B, H, W, Cout)
     return s
 
 
 def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx: bool, reduce_list=None,
-                   deferred=None):
+                   deferred=None, d_out_is_mean=False):
     """d_out: [B,H/2,W/2,Cout] -> gradient w.r.t. the block input [B,H,W,Cin] (or None).
 
     The three weight gradients (and the squeeze-excite ones) feed nothing but the optimiser: they run on a helper
@@ -220,7 +229,7 @@ def block_backward(blk, s, d_out, training, grads: Grads, ws: Workspace, need_dx
     bn2, bns = blk.bn2, blk.shortcut[1]
     ops.resblock_bwd_ew(d_out, s.c2, s.sc, s.coeff2, s.coeffs, s.gate, s.hid, s.gap, s.bsum2, W1, W2, d_c2, d_sc,
                         grads.of(bn2.weight), grads.of(bn2.bias), grads.of(bns.weight), grads.of(bns.bias),
-                        None, None, scratch, B, H, W, Cout, training)
+                        None, None, scratch, B, H, W, Cout, training, dout_is_mean=d_out_is_mean)
     d_h1 = ws.buf(name + ".d_h1", (B, H, W, Cout))
     d_c1 = d_h1                                   # bn_relu_bwd works in place
     d_in = ws.buf(name + ".d_in", (B, H, W, Cin)) if need_dx else None
@@ -357,7 +366,9 @@ def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Works
         pending = side_work[1]()
     for i, blk in enumerate((m.res_block1, m.res_block2, m.res_block3)):
         cout = blk.conv1.weight.shape[0]
-        s = block_forward(blk, f"rb{i + 1}", a, B, h, w, cin, cout, training, need_grad, ws, packs, hook=pending)
+        feat = ws.buf("audio.feat", (B, cout)) if i == 2 and FUSE_GAP else None
+        s = block_forward(blk, f"rb{i + 1}", a, B, h, w, cin, cout, training, need_grad, ws, packs, hook=pending,
+                          mean_out=feat)
         pending = None
         st.blocks.append(s)
         a, h, w, cin = s.out, h // 2, w // 2, cout
@@ -367,19 +378,24 @@ def audio_forward(m, x: torch.Tensor, training: bool, need_grad: bool, ws: Works
     if pending is not None:
         pending()
     st.P, st.C = h * w, cin
-    feat = ws.buf("audio.feat", (B, cin))
-    ops.gap_fwd(a, feat, B, st.P, cin)
+    if not FUSE_GAP:
+        feat = ws.buf("audio.feat", (B, cin))
+        ops.gap_fwd(a, feat, B, st.P, cin)
     return feat, st
 
 
 def audio_backward(m, st, dfeat: torch.Tensor, training: bool, grads: Grads, ws: Workspace):
     B = st.B
-    d = ws.buf("audio.d_last", (B, st.P, st.C))
-    ops.gap_bwd(dfeat.contiguous(), d, B, st.P, st.C)
+    if FUSE_GAP:
+        d = dfeat.contiguous()       # the last block's backward takes the gradient of the pooled mean as it is
+    else:
+        d = ws.buf("audio.d_last", (B, st.P, st.C))
+        ops.gap_bwd(dfeat.contiguous(), d, B, st.P, st.C)
     reduce_list = []
     deferred = [] if WGRAD_DEFER and ws.persistent and FORK_WGRAD and FORK_ANY else None
-    for blk, s in zip((m.res_block3, m.res_block2, m.res_block1), reversed(st.blocks)):
-        d = block_backward(blk, s, d, training, grads, ws, need_dx=True, reduce_list=reduce_list, deferred=deferred)
+    for i, (blk, s) in enumerate(zip((m.res_block3, m.res_block2, m.res_block1), reversed(st.blocks))):
+        d = block_backward(blk, s, d, training, grads, ws, need_dx=True, reduce_list=reduce_list, deferred=deferred,
+                           d_out_is_mean=FUSE_GAP and i == 0)
     fw = fork(ws, dfeat.device).mark() if deferred else None     # the last data-gradient convolution is on its way
     conv0, bn0 = m.conv1[0], m.conv1[1]
     scratch = ws.buf("stem.bwd_scratch", ops.stem_bwd_scratch(B, st.H))

@@ -532,6 +532,15 @@ def res_gate_relu_pool(c2, sc, coeff2, coeffs, gate, out, B, H, W, C):
               B, H, W, C, _stream())
 
 
+def res_gate_relu_pool_mean(c2, sc, coeff2, coeffs, gate, feat, B, H, W, C):
+    """Mean over the pooled positions of what :func:`res_gate_relu_pool` would store: feat [B, C]."""
+    n = B * H * W * C
+    if c2.numel() != n or sc.numel() != n or feat.numel() != B * C or gate.numel() != B * C:
+        raise ValueError("res_gate_relu_pool_mean: bad sizes")
+    _lib.call("mmsa_res_gate_relu_pool_mean", _chk(c2), _chk(sc), _chk(coeff2), _chk(coeffs), _chk(gate), _chk(feat),
+              B, H, W, C, _stream())
+
+
 def gate_affine_add(a, coeff2, gate, sc, coeffs, out, B, P, C, relu: bool):
     """out = [relu]((a * scale2 + shift2) * gate + (sc * scale_s + shift_s)) over [B, P, C] maps; coefficient tables,
     gate and second map are optional (identity / 1 / 0)."""
@@ -566,9 +575,10 @@ def resblock_bwd_scratch(B, H, W, C) -> int:
 
 
 def resblock_bwd_ew(dout, c2, sc, coeff2, coeffs, gate, hid, gap, bsum, W1, W2, d_c2, d_sc, dgamma2, dbeta2,
-                    dgammas, dbetas, dW1, dW2, scratch, B, H, W, C, training):
+                    dgammas, dbetas, dW1, dW2, scratch, B, H, W, C, training, dout_is_mean=False):
+    """dout_is_mean: dout is [B, C], the gradient with respect to the mean of the block's pooled output."""
     n = B * H * W * C
-    if dout.numel() != B * (H // 2) * (W // 2) * C or c2.numel() != n or sc.numel() != n or d_c2.numel() != n \
+    if dout.numel() != (B * C if dout_is_mean else B * (H // 2) * (W // 2) * C) or c2.numel() != n or sc.numel() != n or d_c2.numel() != n \
             or d_sc.numel() != n or scratch.numel() < resblock_bwd_scratch(B, H, W, C):
         raise ValueError("resblock_bwd_ew: bad sizes")
     for t in (dgamma2, dbeta2, dgammas, dbetas):
@@ -578,7 +588,7 @@ def resblock_bwd_ew(dout, c2, sc, coeff2, coeffs, gate, hid, gap, bsum, W1, W2, 
         raise ValueError("resblock_bwd_ew: pass both SE gradients or neither")
     if dW1 is not None and (dW1.numel() != W1.numel() or dW2.numel() != W2.numel()):
         raise ValueError("resblock_bwd_ew: bad SE gradient size")
-    _lib.call("mmsa_resblock_bwd_ew", _chk(dout), _chk(c2), _chk(sc), _chk(coeff2), _chk(coeffs), _chk(gate),
+    _lib.call("mmsa_resblock_bwd_ew_from_mean" if dout_is_mean else "mmsa_resblock_bwd_ew", _chk(dout), _chk(c2), _chk(sc), _chk(coeff2), _chk(coeffs), _chk(gate),
               _chk(hid), _chk(gap), _chk(bsum), _chk(W1), _chk(W2), _chk(d_c2), _chk(d_sc), _chk(dgamma2),
               _chk(dbeta2), _chk(dgammas), _chk(dbetas), _opt(dW1), _opt(dW2), _chk(scratch), B, H, W, C,
               int(training), _stream())

@@ -572,6 +572,48 @@ def test_data_gradient_with_batchnorm_backward_sums_in_its_epilogue(B, H, W, C):
         check(a, b, 2e-6)
 
 
+@pytest.mark.parametrize("B,H,W,C", [(4, 8, 16, 256), (3, 6, 10, 64), (2, 9, 7, 128)])
+def test_global_average_pool_inside_the_last_blocks_pooling_kernels(B, H, W, C):
+    """The last residual block's pooled output only feeds the global average pool: forward, the mean comes straight
+    out of the gate + ReLU + max-pool kernel; backward, the block's element-wise backward takes the gradient of the
+    mean.  Against the two-launch sequences (pooled map + gap_fwd, gap_bwd + gradient map)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(17 + C)
+    rnd = lambda *shape: torch.randn(*shape, generator=g).to(DEV)
+    c2, sc = rnd(B, H, W, C), rnd(B, H, W, C)
+    coeff2, coeffs = rnd(4, C) * 0.5, rnd(4, C) * 0.5
+    coeff2[1], coeffs[1] = coeff2[1].abs() + 0.5, coeffs[1].abs() + 0.5
+    gate = torch.sigmoid(rnd(B, C))
+    H2, W2 = H // 2, W // 2
+    pooled = torch.empty(B, H2, W2, C, device=DEV)
+    ops.res_gate_relu_pool(c2, sc, coeff2.flatten(), coeffs.flatten(), gate, pooled, B, H, W, C)
+    feat_ref = torch.empty(B, C, device=DEV)
+    ops.gap_fwd(pooled, feat_ref, B, H2 * W2, C)
+    feat = torch.empty(B, C, device=DEV)
+    ops.res_gate_relu_pool_mean(c2, sc, coeff2.flatten(), coeffs.flatten(), gate, feat, B, H, W, C)
+    check(feat, pooled.double().mean((1, 2)), 2e-6)
+    check(feat, feat_ref, 2e-6)
+    # backward
+    Ch = C // 16
+    hid, gapv, bsum = rnd(B, Ch).abs(), rnd(B, C), rnd(B, C) * (H * W)
+    W1, W2m = rnd(Ch, C) * 0.1, rnd(C, Ch) * 0.1
+    dfeat = rnd(B, C)
+    dmap = torch.empty(B, H2 * W2, C, device=DEV)
+    ops.gap_bwd(dfeat, dmap, B, H2 * W2, C)
+    outs = []
+    for mean in (False, True):
+        d_c2, d_sc = torch.empty_like(c2), torch.empty_like(c2)
+        gr = [torch.zeros(C, device=DEV) for _ in range(4)]
+        dW1, dW2 = torch.zeros_like(W1), torch.zeros_like(W2m)
+        scratch = torch.zeros(ops.resblock_bwd_scratch(B, H, W, C), device=DEV)
+        ops.resblock_bwd_ew(dfeat if mean else dmap, c2, sc, coeff2.flatten(), coeffs.flatten(), gate, hid, gapv, bsum,
+                            W1, W2m, d_c2, d_sc, gr[0], gr[1], gr[2], gr[3], dW1, dW2, scratch, B, H, W, C, True,
+                            dout_is_mean=mean)
+        outs.append([d_c2, d_sc, *gr, dW1, dW2])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_both_implicit_gemm_kernels_on_every_launch_shape(monkeypatch):
     """Which kernel takes a 3x3 launch (MMSA_IGEMM3 = 0: the general implicit GEMM always; 1: the one that stages an
     input strip once per row of three taps for 32-channel results only; 2, the default: for every 3x3 launch), and
