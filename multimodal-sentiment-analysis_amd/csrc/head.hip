@@ -58,28 +58,34 @@ __device__ __forceinline__ float* mf(const HeadPtrs& h, int s) { return static_c
 // out[n] = bias[n] + sum_k W[n][k] x[k] for n < N (x, out in LDS; K a multiple of 4, rows of W 16-byte aligned).
 // Sixteen lanes share an output row and read it in 16-byte pieces (256 contiguous bytes per row and step), 64 rows
 // per pass over the workgroup; two passes are in flight at a time.
-__device__ __forceinline__ void matvec(const float* __restrict__ W, const float* __restrict__ bias, const float* x,
-                                       float* out, int K, int N) {
+// NIT: 64-column steps a row takes (K <= 64 NIT), so that only the pieces a layer has are requested: every request
+// instruction costs the CU's address unit 16 cycles whether or not its lanes repeat a neighbour's address, and a
+// 64 x 3 layer served with the 8 steps x 2 rows of the largest one spent 1.7 us on 255 redundant kilobytes.
+template <int NIT>
+__device__ __forceinline__ void matvec_steps(const float* __restrict__ W, const float* __restrict__ bias, const float* x,
+                                             float* out, int K, int N) {
   const int t = threadIdx.x, sub = t % LPR, rloc = t / LPR;
   constexpr int RP = HT / LPR;
+  const int wave_row0 = (t >> 6) * (64 / LPR);          // first row of this wave in a pass (uniform per wave)
   for (int n0 = 0; n0 < N; n0 += 2 * RP) {
     const int na = n0 + rloc, nb = n0 + RP + rloc;
+    const bool wave_a = n0 + wave_row0 < N, wave_b = n0 + RP + wave_row0 < N;   // does this wave hold any row of the pass
     const float* wa = W + (long)min(na, N - 1) * K;
     const float* wb = W + (long)min(nb, N - 1) * K;
     float a = 0.f, b = 0.f;
-    // all of a row pair's pieces are requested before any is used (K <= 512: at most 8 steps): one round trip to
-    // memory per pass instead of one per step
-    // (loads are unconditional, from a clamped offset: a load under a run-time condition would be waited for
-    // on its own)
-    f32x4 u[8], v[8];
+    // all of a row pair's pieces are requested before any is used: one round trip to memory per pass instead of one
+    // per step (within a wave that holds rows the loads are unconditional, from a clamped offset: a load under a
+    // per-lane condition would be waited for on its own)
+    f32x4 u[NIT], v[NIT];
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int k = min(4 * sub + it * 4 * LPR, K - 4);
-      u[it] = *reinterpret_cast<const f32x4*>(wa + k);
-      v[it] = *reinterpret_cast<const f32x4*>(wb + k);
+      u[it] = v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (wave_a) u[it] = *reinterpret_cast<const f32x4*>(wa + k);
+      if (wave_b) v[it] = *reinterpret_cast<const f32x4*>(wb + k);
     }
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < NIT; ++it) {
       const int k = 4 * sub + it * 4 * LPR;
       const bool in = k < K;
       const f32x4 x4 = *reinterpret_cast<const f32x4*>(x + (in ? k : 0));
@@ -102,6 +108,16 @@ __device__ __forceinline__ void matvec(const float* __restrict__ W, const float*
   }
 }
 
+__device__ __forceinline__ void matvec(const float* __restrict__ W, const float* __restrict__ bias, const float* x,
+                                       float* out, int K, int N) {
+  const int nit = (K + 4 * LPR - 1) / (4 * LPR);   // uniform
+  if (nit <= 1) matvec_steps<1>(W, bias, x, out, K, N);
+  else if (nit == 2) matvec_steps<2>(W, bias, x, out, K, N);
+  else if (nit <= 4) matvec_steps<4>(W, bias, x, out, K, N);
+  else if (nit <= 6) matvec_steps<6>(W, bias, x, out, K, N);
+  else matvec_steps<8>(W, bias, x, out, K, N);
+}
+
 // dx[k] (= or +=) sum_n g[n] W[n][k] for k < K (g, dx in LDS).  Threads run along k (coalesced rows of W); the sum over
 // n is split over HT / Kp thread groups and combined through `part` ([HT] floats of LDS) in fixed order.
 __device__ __forceinline__ void matvec_t(const float* __restrict__ W, const float* g, float* dx, float* part, int K,
@@ -115,8 +131,13 @@ __device__ __forceinline__ void matvec_t(const float* __restrict__ W, const floa
     // sixteen independent weight loads in flight per thread
     for (int n0 = grp; n0 < N; n0 += 16 * G) {
       float wv[16];
+      // (a thread group is a whole number of waves, so the row tests below are uniform per wave: rows past the end
+      // of a small layer are not requested at all)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) wv[i] = W[(long)min(n0 + i * G, N - 1) * K + kl];   // unconditional loads
+      for (int i = 0; i < 16; ++i) {
+        wv[i] = 0.f;
+        if (n0 + i * G < N) wv[i] = W[(long)(n0 + i * G) * K + kl];
+      }
 #pragma unroll
       for (int i = 0; i < 16; i += 4) {
         const int n = n0 + i * G;
