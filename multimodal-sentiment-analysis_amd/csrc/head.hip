@@ -118,42 +118,41 @@ __device__ __forceinline__ void matvec(const float* __restrict__ W, const float*
   else matvec_steps<8>(W, bias, x, out, K, N);
 }
 
-// dx[k] (= or +=) sum_n g[n] W[n][k] for k < K (g, dx in LDS).  Threads run along k (coalesced rows of W); the sum over
-// n is split over HT / Kp thread groups and combined through `part` ([HT] floats of LDS) in fixed order.
+// dx[k] (= or +=) sum_n g[n] W[n][k] for k < K (g, dx in LDS; K a multiple of 4, rows of W 16-byte aligned).  A thread
+// takes four consecutive k (16-byte pieces of the rows of W, coalesced), KQ = K / 4 rounded up to whole waves threads
+// span a row, and the sum over n is split over G = HT / KQ thread groups (whole waves, so their row tests are uniform);
+// sixteen row pieces are in flight per thread -- four times the bytes per round trip of a dword per thread, which is
+// what the two projectors' 256 x 256 and 256 x 384 matrices need (one and two round trips instead of four and eight).
+// The groups' partial sums meet in `part` ([4 * HT] floats of LDS) and are added in group order.
 __device__ __forceinline__ void matvec_t(const float* __restrict__ W, const float* g, float* dx, float* part, int K,
                                          int N, bool accumulate) {
   const int t = threadIdx.x;
-  const int Kp = (K + 63) & ~63;
-  const int G = HT / Kp;
-  const int kl = t % Kp, grp = t / Kp;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (kl < K && grp < G) {
-    // sixteen independent weight loads in flight per thread
-    for (int n0 = grp; n0 < N; n0 += 16 * G) {
-      float wv[16];
-      // (a thread group is a whole number of waves, so the row tests below are uniform per wave: rows past the end
-      // of a small layer are not requested at all)
+  const int KQ = ((K >> 2) + 63) & ~63;
+  const int G = HT / KQ;
+  const int kq = t % KQ, grp = t / KQ;
+  const bool active = 4 * kq < K;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int n0 = grp; n0 < N; n0 += 16 * G) {   // uniform per wave
+    f32x4 wv[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        wv[i] = 0.f;
-        if (n0 + i * G < N) wv[i] = W[(long)(n0 + i * G) * K + kl];
-      }
+    for (int i = 0; i < 16; ++i) {
+      wv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (n0 + i * G < N && active) wv[i] = *reinterpret_cast<const f32x4*>(W + (long)(n0 + i * G) * K + 4 * kq);
+    }
 #pragma unroll
-      for (int i = 0; i < 16; i += 4) {
-        const int n = n0 + i * G;
-        a0 = fmaf(n < N ? g[n] : 0.f, wv[i], a0);
-        a1 = fmaf(n + G < N ? g[n + G] : 0.f, wv[i + 1], a1);
-        a2 = fmaf(n + 2 * G < N ? g[n + 2 * G] : 0.f, wv[i + 2], a2);
-        a3 = fmaf(n + 3 * G < N ? g[n + 3 * G] : 0.f, wv[i + 3], a3);
-      }
+    for (int i = 0; i < 16; ++i) {
+      const int n = n0 + i * G;
+      const float gn = n < N ? g[n] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(gn, wv[i][e], acc[e]);
     }
   }
   __syncthreads();   // the previous user of `part` is done
-  part[t] = (a0 + a1) + (a2 + a3);
+  *reinterpret_cast<f32x4*>(part + 4 * t) = acc;
   __syncthreads();
   if (t < K) {
     float s = 0.f;
-    for (int i = 0; i < G; ++i) s += part[i * Kp + t];
+    for (int i = 0; i < G; ++i) s += part[4 * (i * KQ + (t >> 2)) + (t & 3)];
     dx[t] = accumulate ? dx[t] + s : s;
   }
   __syncthreads();
@@ -337,7 +336,7 @@ __global__ __launch_bounds__(HT) void head_both_bwd_kernel(const HeadPtrs h, con
   __shared__ float s_d[1024];     // gradient w.r.t. the current layer's output
   __shared__ float s_g[1024];     // gradient w.r.t. the current layer's linear output
   __shared__ float s_dP[1024];    // gradient w.r.t. the projected audio | text
-  __shared__ float part[HT];
+  __shared__ __attribute__((aligned(16))) float part[4 * HT];
   const int b = blockIdx.x, t = threadIdx.x;
   const int A = d.A, T = d.T, Hd = d.Hd, N0 = d.N0, N1 = d.N1, C = d.C;
   const unsigned long long seed = step_seed(h, d.seed);
