@@ -349,14 +349,19 @@ __device__ __forceinline__ void bn_finalize_body(const float* __restrict__ parti
                                                  float eps, int training, float* __restrict__ coeff,
                                                  float* __restrict__ bsum, int C) {
   __shared__ double red[16];
+  constexpr int STASH = 2048;          // rows of the channel's sums kept in LDS for the per-utterance pass below
+  __shared__ float stash[STASH];
   const int c = blockIdx.x;
   if (training && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
   const float* ps = partial + (long)c * rows;
   const float* pq = partial + ((long)C + c) * rows;
+  const bool stashed = training && bsum && rows <= STASH;   // uniform
   double s = 0.0, q = 0.0;
   if (training) {
     for (int r = threadIdx.x; r < rows; r += 256) {
-      s += (double)ps[r];
+      const float v = ps[r];
+      if (stashed) stash[r] = v;
+      s += (double)v;
       q += (double)pq[r];
     }
     s = block_sum_d(s, red);
@@ -390,9 +395,14 @@ __device__ __forceinline__ void bn_finalize_body(const float* __restrict__ parti
     // eight lanes per utterance: each takes every eighth tile, the eight sums meet through lane exchanges
     const int B = rows / tiles_per_img;
     const int sub = threadIdx.x & 7;
+    // (the sums were read once already: from LDS this pass costs no further trips to memory -- each lane's chain of
+    // up to five dependent loads was half of the kernel's time on the first block's 1 056 rows)
     for (int b = threadIdx.x >> 3; b < B; b += 32) {
       float t = 0.f;
-      for (int i = sub; i < tiles_per_img; i += 8) t += ps[(long)b * tiles_per_img + i];
+      if (stashed)
+        for (int i = sub; i < tiles_per_img; i += 8) t += stash[b * tiles_per_img + i];
+      else
+        for (int i = sub; i < tiles_per_img; i += 8) t += ps[(long)b * tiles_per_img + i];
       t += __shfl_xor(t, 1, 64);
       t += __shfl_xor(t, 2, 64);
       t += __shfl_xor(t, 4, 64);
@@ -466,11 +476,25 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   // next sixteen; each unit's sum keeps its order
   for (int j0 = w; j0 < Ch; j0 += 16) {
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = lane; c < C; c += 64) {
-      const float gc = g[c];
+    // C <= 256: at most four 64-channel steps, whose sixteen weights are all requested before the first is used (one
+    // trip to memory instead of four); the sums keep their order
+    float wv[4][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (j0 + 4 * u < Ch) a[u] = fmaf(W1[(long)(j0 + 4 * u) * C + c], gc, a[u]);
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = lane + 64 * it;
+        wv[it][u] = (c < C && j0 + 4 * u < Ch) ? W1[(long)(j0 + 4 * u) * C + c] : 0.f;
+      }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int c = lane + 64 * it;
+      if (c < C) {
+        const float gc = g[c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + 4 * u < Ch) a[u] = fmaf(wv[it][u], gc, a[u]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -759,11 +783,23 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ p
   // sixteen; each unit's sum keeps its order
   for (int j0 = w; j0 < Ch; j0 += 16) {
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int c = lane; c < C; c += 64) {
-      const float uc = sdu[c];
+    float wv[4][4];       // C <= 256: all sixteen weights of the wave's four units requested at once
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (j0 + 4 * u < Ch) a[u] = fmaf(W2[(long)c * Ch + j0 + 4 * u], uc, a[u]);
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = lane + 64 * it;
+        wv[it][u] = (c < C && j0 + 4 * u < Ch) ? W2[(long)c * Ch + j0 + 4 * u] : 0.f;
+      }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int c = lane + 64 * it;
+      if (c < C) {
+        const float uc = sdu[c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (j0 + 4 * u < Ch) a[u] = fmaf(wv[it][u], uc, a[u]);
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -780,7 +816,14 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ p
   if (t < C) {
     float a = 0.f;
     int j = 0;
-    for (; j + 4 <= Ch; j += 4) {              // four weight loads in flight; the sum keeps its order
+    for (; j + 16 <= Ch; j += 16) {            // sixteen weight loads in flight; the sum keeps its order
+      float wj[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) wj[i] = W1[(long)(j + i) * C + t];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a = fmaf(wj[i], sdh[j + i], a);
+    }
+    for (; j + 4 <= Ch; j += 4) {              // four weight loads in flight
       const float w0 = W1[(long)j * C + t], w1 = W1[(long)(j + 1) * C + t];
       const float w2 = W1[(long)(j + 2) * C + t], w3 = W1[(long)(j + 3) * C + t];
       a = fmaf(w0, sdh[j], a); a = fmaf(w1, sdh[j + 1], a); a = fmaf(w2, sdh[j + 2], a); a = fmaf(w3, sdh[j + 3], a);
