@@ -335,27 +335,30 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
 #ifdef MMSA_LAB_STAMPS
   const unsigned long long lab_t1 = __builtin_amdgcn_s_memtime();
 #endif
-  for (int k = 0; k < count; ++k) {
+  // The strip loop once per tap group, chosen outside it (the choice is the same for a wave's whole life): with the
+  // choice inside the loop the compiler kept one set of accumulators per branch and copied 80 registers at every join.
+  auto strips = [&](auto qsel_tag) {
+    for (int k = 0; k < count; ++k) {
 #ifdef MMSA_LAB_STAMPS
-    lab_t = __builtin_amdgcn_s_memtime();
+      lab_t = __builtin_amdgcn_s_memtime();
 #endif
-    // the next strip streams into the other buffer (drained one barrier ago) under this strip's matrix work
-    if (k + 1 < count) request(k + 1);
-    const char* buf = reinterpret_cast<const char*>(lds + (k & 1) * buf_fl);
-    if (nmine > 0) {
-      if (q == 0) strip(buf, std::integral_constant<int, 0>{});
-      else if (SC) strip(buf, std::integral_constant<int, 2>{});
-      else strip(buf, std::integral_constant<int, 1>{});
+      // the next strip streams into the other buffer (drained one barrier ago) under this strip's matrix work
+      if (k + 1 < count) request(k + 1);
+      const char* buf = reinterpret_cast<const char*>(lds + (k & 1) * buf_fl);
+      if (nmine > 0) strip(buf, qsel_tag);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef MMSA_LAB_STAMPS
+      { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); lab_comp += n_ - lab_t; lab_t = n_; }
+#endif
+      __builtin_amdgcn_s_barrier();
+#ifdef MMSA_LAB_STAMPS
+      lab_wait += __builtin_amdgcn_s_memtime() - lab_t;
+#endif
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#ifdef MMSA_LAB_STAMPS
-    { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); lab_comp += n_ - lab_t; lab_t = n_; }
-#endif
-    __builtin_amdgcn_s_barrier();
-#ifdef MMSA_LAB_STAMPS
-    lab_wait += __builtin_amdgcn_s_memtime() - lab_t;
-#endif
-  }
+  };
+  if (q == 0) strips(std::integral_constant<int, 0>{});
+  else if (SC) strips(std::integral_constant<int, 2>{});
+  else strips(std::integral_constant<int, 1>{});
 #ifdef MMSA_LAB_STAMPS
   const unsigned long long lab_t2 = __builtin_amdgcn_s_memtime();
 #endif
