@@ -236,6 +236,28 @@ def train_batches(n_items: int, per_rank_batch: int, epoch_seed: int, rank: int,
     return out
 
 
+def broadcast_buffers(module: torch.nn.Module, src: int = 0, group=None):
+    """Copies rank ``src``'s module buffers (BatchNorm running statistics and batch counts) to every rank.
+
+    Gradients are averaged over ranks, so parameters stay identical; BatchNorm's batch statistics are taken per rank
+    (each rank normalises its own 32 utterances, as the single-process reference normalises its batch), so the
+    RUNNING statistics drift apart between replicas.  Call this before evaluation or before writing a checkpoint on a
+    rank other than ``src``, so that every replica scores with the statistics rank ``src`` would save."""
+    rank, world = world_info(group)
+    if world == 1:
+        return
+    direct = dist.get_backend(group) == "nccl"
+    for b in module.buffers():
+        if direct and b.is_cuda:
+            dist.broadcast(b, group_src=src, group=group)
+        else:
+            # group_src keeps this independent of how the group's ranks map to global ranks
+            h = b.detach().to("cpu", copy=True)
+            dist.broadcast(h, group_src=src, group=group)
+            if rank != src:
+                b.copy_(h)
+
+
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous inference shard [lo, hi): ceil(n/world) items per rank, the last ranks may get fewer or none."""
     per = (n_items + world - 1) // world

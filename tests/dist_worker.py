@@ -87,8 +87,30 @@ def main():
     ex.finish(table, ex.start())
     torch.cuda.synchronize()
     exact = bool(torch.equal(table, dense))
+    # sharded inference (multimodal_test.py --modality both over several GPUs): each rank scores its contiguous shard
+    # of a 21-utterance test set (ragged: 11 + 10) on the GPU, the predictions are gathered back into dataset order on
+    # every rank, and must equal what one process gets for the whole set with the same (trained, replicated) weights
+    # BatchNorm's running statistics are per rank (each rank normalises its own batch): every replica takes rank 0's,
+    # the ones a checkpoint written by rank 0 would hold
+    bn_before = torch.cat([b.detach().flatten().float().cpu() for b in m.buffers()])
+    parallel.broadcast_buffers(m)
+    bn_after = torch.cat([b.detach().flatten().float().cpu() for b in m.buffers()])
+    assert (rank == 0) == bool(torch.equal(bn_before, bn_after)), "the ranks' running statistics should have differed"
+    m.eval()
+    n_test = 21
+    test = batch_tensors(1000, n_test, vocab=SMALL_VOCAB, device="cuda")
+    with torch.no_grad():
+        whole = m(audio=test["audio"], input_ids=test["input_ids"])
+        lo, hi = parallel.shard_range(n_test, rank, world)
+        mine = m(audio=test["audio"][lo:hi], input_ids=test["input_ids"][lo:hi])
+    probs, preds = mine["probabilities"], mine["probabilities"].argmax(1)
+    gp, gr = parallel.gather_predictions(probs, preds, n_test)
+    torch.cuda.synchronize()
+    infer_err = float((gp - whole["probabilities"]).abs().max())
+    infer_ok = bool(gp.shape == (n_test, 3) and gp.is_cuda and torch.equal(gr, whole["probabilities"].argmax(1)))
     torch.save({"flat": m._arena.flat.cpu(), "losses": losses, "sparse": bool(ts._use_sparse),
-                "exchange_exact": exact}, f"{prefix}.rank{rank}.pt")
+                "exchange_exact": exact, "infer_err": infer_err, "infer_ok": infer_ok, "infer_probs": gp.cpu(), "buffers": bn_after},
+               f"{prefix}.rank{rank}.pt")
     dist.barrier()
     dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()

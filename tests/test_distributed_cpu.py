@@ -80,7 +80,14 @@ def _worker(rank, world, port, ret):
             differs = False
         except RuntimeError:
             differs = True
-        ret[rank] = (err, (ok, sparse_ok, differs, direct_ok), [b.tolist() for b in tb])
+        # BatchNorm running statistics are per rank: broadcast_buffers gives every replica rank 0's
+        bn = torch.nn.BatchNorm1d(4)
+        bn.running_mean.fill_(float(rank + 1))
+        bn.num_batches_tracked.fill_(10 * (rank + 1))
+        parallel.broadcast_buffers(bn)
+        buffers_ok = (bool((bn.running_mean == 1.0).all()) and int(bn.num_batches_tracked) == 10
+                      and bool((bn.running_var == 1.0).all()))
+        ret[rank] = (err, (ok, sparse_ok, differs, direct_ok, buffers_ok), [b.tolist() for b in tb])
     finally:
         dist.destroy_process_group()
 

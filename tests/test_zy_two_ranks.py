@@ -67,6 +67,12 @@ def test_two_ranks_sharing_one_gpu(use_graph, tmp_path):
     embedding table's gradient travels row-sparse here (MMSA_SPARSE_EMB=1), so both exchanges are under test."""
     r0, r1 = _run_two_ranks(use_graph, str(tmp_path / "dp"), 29800, MMSA_SPARSE_EMB="1")
     assert r0["sparse"] is True
+    # sharded inference behind the training steps (see dist_worker.py): gathered predictions in dataset order, equal on
+    # both ranks and equal to one process scoring the whole set (per-utterance results do not depend on the batch
+    # they are scored in beyond rounding of the tiled reductions)
+    assert torch.equal(r0["buffers"], r1["buffers"])          # running statistics broadcast from rank 0
+    assert r0["infer_ok"] and r1["infer_ok"] and torch.equal(r0["infer_probs"], r1["infer_probs"])
+    assert max(r0["infer_err"], r1["infer_err"]) < 1e-5, (r0["infer_err"], r1["infer_err"])
 
     m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
     m.fusion_layer.draw_modality_dropout = lambda: (False, False)
