@@ -326,7 +326,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
   };
 
 #ifdef MMSA_LAB_STAMPS
-  const unsigned long long lab_t0 = __builtin_amdgcn_s_memtime();
+  const unsigned long long lab_t0 = __builtin_amdgcn_s_memtime(), lab_r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long lab_comp = 0, lab_wait = 0, lab_t;
 #endif
   request(0);
@@ -406,6 +406,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
     o[2] = lab_wait;                                 // barriers behind them
     o[3] = __builtin_amdgcn_s_memtime() - lab_t2;    // reduction through LDS and slab stores
     o[4] = __builtin_amdgcn_s_memtime() - lab_t0;
+    o[5] = __builtin_amdgcn_s_memrealtime() - lab_r0;   // 100 MHz ticks: o[4] / o[5] * 0.1 = the wave's clock in GHz
   }
 #endif
 }

@@ -69,13 +69,14 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(hs.data(), stamps, nst * 8, hipMemcpyDeviceToHost));
   const int nwg = (Cin / 32) * (Cout / 64) * nslabs;
   for (int q = 0; q < 4; q += 2) {
-    std::vector<double> v[5];
+    std::vector<double> v[6];
     for (int w = 0; w < nwg; ++w)
-      for (int k = 0; k < 5; ++k) v[k].push_back((double)hs[((size_t)w * 4 + q) * 8 + k]);
-    double med[5];
-    for (int k = 0; k < 5; ++k) { std::sort(v[k].begin(), v[k].end()); med[k] = v[k][v[k].size() / 2]; }
+      for (int k = 0; k < 6; ++k) v[k].push_back((double)hs[((size_t)w * 4 + q) * 8 + k]);
+    double med[6];
+    for (int k = 0; k < 6; ++k) { std::sort(v[k].begin(), v[k].end()); med[k] = v[k][v[k].size() / 2]; }
     printf("  wave q=%d: median cycles first strip %.0f, matrix loops %.0f, barrier waits %.0f, slab stores %.0f, total %.0f\n",
            q / 2, med[0], med[1], med[2], med[3], med[4]);
+    printf("           wave lifetime %.2f us at %.2f GHz\n", med[5] / 100.0, med[4] / med[5] * 0.1);
   }
 #endif
   return 0;
