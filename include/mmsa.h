@@ -357,11 +357,13 @@ MMSA_API int mmsa_grad_norm(const float* g, const float* p, const float* tnorm, 
 MMSA_API int mmsa_grad_norm_finish(const float* g, const float* p, const float* tnorm, float lambda,
                                    const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,
                                    const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* state,
-                                   float beta1, float beta2, float max_norm, int do_clip, void* stream);
-/* state (8 floats): 0 step, 1 1-beta1^t, 2 sqrt(1-beta2^t), 3 clip coefficient, 4 total grad norm, 5 sum of norms */
+                                   double beta1, double beta2, float max_norm, int do_clip, void* stream);
+/* state (8 floats): 0 step, 1 1-beta1^t, 2 sqrt(1-beta2^t), 3 clip coefficient, 4 total grad norm, 5 sum of norms.
+ * The betas are doubles: torch.optim.AdamW forms 1 - beta and the bias corrections in double before anything is rounded
+ * to fp32 (1 - 0.999 -> 0.001f, where 1.f - 0.999f = 0.00099998713f). */
 MMSA_API int mmsa_adamw_step(float* p, const float* g, float* m, float* v, const long long* chunk_off,
                              const int* chunk_len, const int* chunk_tensor, int nchunks, const float* tnorm,
-                             float lambda, float* state, float lr, float beta1, float beta2, float eps,
+                             float lambda, float* state, float lr, double beta1, double beta2, float eps,
                              float weight_decay, float max_norm, int do_clip, double* chunk_ss_new, int scalars_ready,
                              void* stream);
 MMSA_API int mmsa_scale_by_state(float* g, long n, const float* state, int idx, void* stream);

@@ -62,12 +62,14 @@ __global__ __launch_bounds__(256) void chunk_sumsq_kernel(const float* __restric
 }
 
 // One thread: advances the step count and derives the bias corrections and the clip coefficient from the total norm.
-__device__ __forceinline__ void step_scalars(float* __restrict__ state, float beta1, float beta2, float max_norm,
+// (The bias corrections are formed in double from the double betas, as torch.optim.AdamW forms them on the host:
+// with fp32 betas 1 - 0.999f^t is 1.3e-5 off at t = 1.)
+__device__ __forceinline__ void step_scalars(float* __restrict__ state, double beta1, double beta2, float max_norm,
                                              int do_clip, float gnorm) {
   const float t = state[ST_STEP] + 1.f;
   state[ST_STEP] = t;
-  state[ST_BC1] = 1.f - powf(beta1, t);
-  state[ST_BC2S] = sqrtf(1.f - powf(beta2, t));
+  state[ST_BC1] = (float)(1.0 - pow(beta1, (double)t));
+  state[ST_BC2S] = (float)sqrt(1.0 - pow(beta2, (double)t));
   float coef = 1.f;
   if (do_clip) coef = fminf(max_norm / (gnorm + 1e-6f), 1.f);
   state[ST_CLIP] = coef;
@@ -75,7 +77,8 @@ __device__ __forceinline__ void step_scalars(float* __restrict__ state, float be
 
 struct StepScalars {   // state == nullptr: tensor_norms_kernel leaves the step scalars alone
   float* state;
-  float beta1, beta2, max_norm;
+  double beta1, beta2;
+  float max_norm;
   int do_clip;
 };
 
@@ -125,7 +128,7 @@ __global__ void l2_grad_add_kernel(float* __restrict__ g, const float* __restric
   for (int i = threadIdx.x; i < n; i += blockDim.x) pg[i] = fmaf(coef, pp[i], pg[i]);
 }
 
-__global__ void step_scalars_kernel(float* __restrict__ state, float beta1, float beta2, float max_norm, int do_clip) {
+__global__ void step_scalars_kernel(float* __restrict__ state, double beta1, double beta2, float max_norm, int do_clip) {
   step_scalars(state, beta1, beta2, max_norm, do_clip, state[ST_GNORM]);
 }
 
@@ -136,11 +139,14 @@ __global__ void scale_inplace_by_state_kernel(float* __restrict__ g, long n, con
 }
 
 __device__ __forceinline__ void adamw_update(float& p, float g, float& m, float& v, float coef, float clip, float decay,
-                                             float beta1, float beta2, float bc2s, float eps, float step_size) {
+                                             float omb1, float beta2, float omb2, float bc2s, float eps,
+                                             float step_size) {
+  // omb1 / omb2: 1 - beta rounded to fp32 from the double difference (0.1f, 0.001f), the scalars torch's lerp_ and
+  // addcmul_ receive; 1.f - 0.999f would be 0.00099998713
   const float gr = fmaf(coef, p, g) * clip;      // data gradient + lambda * p / ||p||, then the clip coefficient
   p *= decay;
-  m = m + (1.f - beta1) * (gr - m);
-  v = v * beta2 + (1.f - beta2) * gr * gr;
+  m = m + omb1 * (gr - m);
+  v = v * beta2 + omb2 * gr * gr;
   p -= step_size * (m / (sqrtf(v) / bc2s + eps));
 }
 
@@ -152,8 +158,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     const int* __restrict__ chunk_len,
                                                     const int* __restrict__ chunk_tensor,
                                                     const float* __restrict__ tnorm, float lambda,
-                                                    const float* __restrict__ state, float lr, float beta1, float beta2,
-                                                    float eps, float wd, double* __restrict__ chunk_ss_new) {
+                                                    const float* __restrict__ state, float lr, float omb1, float beta2,
+                                                    float omb2, float eps, float wd,
+                                                    double* __restrict__ chunk_ss_new) {
   __shared__ double red[16];
   double ss = 0.0;   // sum of squares of the UPDATED parameters of this chunk (next step's regulariser norms)
   const float clip = state[ST_CLIP], bc1 = state[ST_BC1], bc2s = state[ST_BC2S];
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       float pk = pp[k], mk = mm[k], vk = vv[k];
-      adamw_update(pk, gg[k], mk, vk, coef, clip, decay, beta1, beta2, bc2s, eps, step_size);
+      adamw_update(pk, gg[k], mk, vk, coef, clip, decay, omb1, beta2, omb2, bc2s, eps, step_size);
       pp[k] = pk;
       mm[k] = mk;
       vv[k] = vk;
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     v4[i] = vv;
   }
   for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
-    adamw_update(p[off + i], g[off + i], m[off + i], v[off + i], coef, clip, decay, beta1, beta2, bc2s, eps, step_size);
+    adamw_update(p[off + i], g[off + i], m[off + i], v[off + i], coef, clip, decay, omb1, beta2, omb2, bc2s, eps, step_size);
     ss += (double)p[off + i] * (double)p[off + i];
   }
   if (chunk_ss_new) {   // uniform
@@ -284,7 +291,7 @@ MMSA_EXPORT int mmsa_grad_norm(const float* g, const float* p, const float* tnor
 MMSA_EXPORT int mmsa_grad_norm_finish(const float* g, const float* p, const float* tnorm, float lambda,
                                       const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
                                       int nchunks, const int* tensor_first_chunk, int ntensors, double* chunk_ss,
-                                      float* state, float beta1, float beta2, float max_norm, int do_clip,
+                                      float* state, double beta1, double beta2, float max_norm, int do_clip,
                                       void* stream) {
   MMSA_REQUIRE(g && chunk_off && chunk_len && chunk_tensor && tensor_first_chunk && chunk_ss && state);
   MMSA_REQUIRE(nchunks > 0 && ntensors > 0 && ntensors <= 1024);
@@ -304,7 +311,7 @@ MMSA_EXPORT int mmsa_grad_norm_finish(const float* g, const float* p, const floa
 // the coefficients in state[] were already advanced for this step by mmsa_grad_norm_finish.
 MMSA_EXPORT int mmsa_adamw_step(float* p, const float* g, float* m, float* v, const long long* chunk_off,
                                 const int* chunk_len, const int* chunk_tensor, int nchunks, const float* tnorm,
-                                float lambda, float* state, float lr, float beta1, float beta2, float eps,
+                                float lambda, float* state, float lr, double beta1, double beta2, float eps,
                                 float weight_decay, float max_norm, int do_clip, double* chunk_ss_new,
                                 int scalars_ready, void* stream) {
   MMSA_REQUIRE(p && g && m && v && state && chunk_off && chunk_len && chunk_tensor && nchunks > 0);
@@ -312,7 +319,8 @@ MMSA_EXPORT int mmsa_adamw_step(float* p, const float* g, float* m, float* v, co
   if (!scalars_ready)
     hipLaunchKernelGGL(step_scalars_kernel, dim3(1), dim3(1), 0, s, state, beta1, beta2, max_norm, do_clip);
   hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, s, p, g, m, v, chunk_off, chunk_len, chunk_tensor, tnorm,
-                     lambda, state, lr, beta1, beta2, eps, weight_decay, chunk_ss_new);
+                     lambda, state, lr, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), eps, weight_decay,
+                     chunk_ss_new);
   return mmsa_launch_status();
 }
 

@@ -163,9 +163,9 @@ def test_clip_and_adamw_over_the_models_flat_buffer_follow_the_formulas():
     assert bool((diff[solid] < bar[solid]).all()) and int(solid.sum()) > 9_000_000, float((diff - bar)[solid].max())
     assert float(diff[used].max()) <= 2.0 * lr and float(diff[~used].max()) == 0.0     # gaps stay untouched
     assert torch.allclose(mom.double()[used], m1[used], rtol=1e-5, atol=1e-12)
-    # the kernel forms 1 - beta2 in fp32 from the fp32 beta2: 0.00099998713 (1.3e-5 below 0.001), and its bias
-    # correction from the same number, so the corrected second moment -- what the step divides by -- is unaffected
-    assert torch.allclose(var.double()[used], v1[used], rtol=3e-5, atol=1e-16)
+    # (1 - beta2 reaches the kernel as the fp32 rounding of the double difference, 0.001f, as in torch; formed in fp32
+    # from the fp32 beta2 it would be 0.00099998713, 1.3e-5 off: this bar tells the two apart)
+    assert torch.allclose(var.double()[used], v1[used], rtol=2e-6, atol=1e-16)
 
 
 def test_front_end_output_is_standardised_per_utterance_at_batch_32():
