@@ -209,6 +209,13 @@ MMSA_API int mmsa_res_gate_relu_pool(const float* c2, const float* sc, const flo
  * (multimodal_model.py:123-125): feat[B][C] = mean over the pooled positions, no pooled map is stored */
 MMSA_API int mmsa_res_gate_relu_pool_mean(const float* c2, const float* sc, const float* coeff2, const float* coeffs,
                                           const float* gate, float* feat, int B, int H, int W, int C, void* stream);
+/* mmsa_se_gate followed by mmsa_res_gate_relu_pool (feat null) or mmsa_res_gate_relu_pool_mean (out null) in one
+ * launch, the same values bit for bit: every workgroup works its utterance's gate out for itself.
+ * multimodal_model.py:38-42,64-70,123-125. */
+MMSA_API int mmsa_res_se_gate_relu_pool(const float* c2, const float* sc, const float* coeff2, const float* coeffs,
+                                        const float* bsum, const float* W1, const float* W2, float* gap, float* hid,
+                                        float* gate, float* out, float* feat, int B, int H, int W, int C, int Ch,
+                                        void* stream);
 /* the block tail without the pooling, every part optional: out = [relu]((a*scale2+shift2)*gate + (sc*scale_s+shift_s));
  * null coefficient table = identity, null gate = 1, null sc = 0: SEBlock.forward alone (multimodal_model.py:38-42:
  * x * gate) and ResidualBlock.forward alone (:64-70, identity or projection shortcut) */

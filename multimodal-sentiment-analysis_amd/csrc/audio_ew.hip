@@ -457,18 +457,18 @@ __global__ void bn_relu_apply_kernel(const f32x4* __restrict__ x, const float* _
 }
 
 // ------------------------------------------------------------------------------------------------ squeeze-excite
-// one block per utterance.  gap = scale*mean_hw(raw) + shift; hid = relu(W1 gap); gate = sigmoid(W2 hid)
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ bsum, const float* __restrict__ coeff,
-                                                      const float* __restrict__ W1, const float* __restrict__ W2,
-                                                      float inv_hw, float* __restrict__ gap, float* __restrict__ hid,
-                                                      float* __restrict__ gate, int C, int Ch) {
-  __shared__ float g[256];
-  __shared__ float hd[16];
-  const int b = blockIdx.x, t = threadIdx.x;
+// Squeeze-excite gate of utterance b by one 256-thread workgroup: gap = scale * mean_hw(raw) + shift; hid = relu(W1 gap);
+// gate = sigmoid(W2 hid).  The gate is left in gs[C] (LDS; valid behind the function's last barrier); with `save` the
+// three vectors also go to memory (the backward pass reads them).  g[256], hd[16], gs[256]: LDS of the caller.
+__device__ __forceinline__ void se_gate_body(const float* __restrict__ bsum, const float* __restrict__ coeff,
+                                             const float* __restrict__ W1, const float* __restrict__ W2, float inv_hw,
+                                             float* __restrict__ gap, float* __restrict__ hid, float* __restrict__ gate,
+                                             int b, int C, int Ch, bool save, float* g, float* hd, float* gs) {
+  const int t = threadIdx.x;
   if (t < C) {
     const float v = fmaf(coeff[2 * C + t], bsum[(long)b * C + t] * inv_hw, coeff[3 * C + t]);
     g[t] = v;
-    gap[(long)b * C + t] = v;
+    if (save) gap[(long)b * C + t] = v;
   }
   __syncthreads();
   const int lane = t & 63, w = t >> 6;
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
       const float v = fmaxf(wave_sum(a[u]), 0.f);
       if (lane == 0 && j0 + 4 * u < Ch) {
         hd[j0 + 4 * u] = v;
-        hid[(long)b * Ch + j0 + 4 * u] = v;
+        if (save) hid[(long)b * Ch + j0 + 4 * u] = v;
       }
     }
   }
@@ -516,7 +516,75 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
       a = fmaf(w4[2], hd[j + 2], a); a = fmaf(w4[3], hd[j + 3], a);
     }
     for (; j < Ch; ++j) a = fmaf(wr[j], hd[j], a);
-    gate[(long)b * C + t] = 1.0f / (1.0f + expf(-a));
+    const float s = 1.0f / (1.0f + expf(-a));
+    gs[t] = s;
+    if (save) gate[(long)b * C + t] = s;
+  }
+  __syncthreads();
+}
+
+// one block per utterance
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ bsum, const float* __restrict__ coeff,
+                                                      const float* __restrict__ W1, const float* __restrict__ W2,
+                                                      float inv_hw, float* __restrict__ gap, float* __restrict__ hid,
+                                                      float* __restrict__ gate, int C, int Ch) {
+  __shared__ float g[256], gs[256];
+  __shared__ float hd[16];
+  se_gate_body(bsum, coeff, W1, W2, inv_hw, gap, hid, gate, blockIdx.x, C, Ch, true, g, hd, gs);
+}
+
+// The squeeze-excite gate and the pooling that consumes it in one launch: grid = (chunks, B); every workgroup works the
+// gate of its utterance out for itself (a few thousand multiply-adds on vectors that sit in L2; its map loads are in
+// flight meanwhile), chunk 0 also stores gap / hid / gate for the backward pass; then
+// out[b][h2][w2][c] = max over the 2x2 window of relu( bn2(c2)*gate[b][c] + bn_s(sc) ), QUADS channel quads per thread.
+constexpr int SEPOOL_QUADS = 2;
+__global__ __launch_bounds__(256) void res_segate_relu_pool_kernel(
+    const float* __restrict__ c2, const float* __restrict__ sc, const float* __restrict__ coeff2,
+    const float* __restrict__ coeffs, const float* __restrict__ bsum, const float* __restrict__ fc1,
+    const float* __restrict__ fc2, float inv_hw, float* __restrict__ gap, float* __restrict__ hid,
+    float* __restrict__ gate, float* __restrict__ out, int H, int W, int C, int Ch) {
+  __shared__ float g[256], gs[256];
+  __shared__ float hd[16];
+  const int b = blockIdx.y;
+  const int H2 = H / 2, W2 = W / 2, c4n = C >> 2;
+  const int per_utt = H2 * W2 * c4n;                       // channel quads of one utterance's pooled map
+  // this thread's quads and their eight map loads each, requested ahead of the gate
+  f32x4 a[SEPOOL_QUADS][4], s[SEPOOL_QUADS][4];
+  int idx[SEPOOL_QUADS];
+#pragma unroll
+  for (int q = 0; q < SEPOOL_QUADS; ++q) {
+    const int i = ((int)blockIdx.x * SEPOOL_QUADS + q) * 256 + (int)threadIdx.x;
+    idx[q] = i < per_utt ? i : -1;
+    if (idx[q] >= 0) {
+      const int c = (i % c4n) * 4;
+      const int r = i / c4n;
+      const int w2 = r % W2, h2 = r / W2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long off = (((long)b * H + 2 * h2 + (k >> 1)) * W + 2 * w2 + (k & 1)) * C + c;
+        a[q][k] = *reinterpret_cast<const f32x4*>(c2 + off);
+        s[q][k] = *reinterpret_cast<const f32x4*>(sc + off);
+      }
+    }
+  }
+  se_gate_body(bsum, coeff2, fc1, fc2, inv_hw, gap, hid, gate, b, C, Ch, blockIdx.x == 0, g, hd, gs);
+#pragma unroll
+  for (int q = 0; q < SEPOOL_QUADS; ++q) {
+    if (idx[q] < 0) continue;
+    const int c = (idx[q] % c4n) * 4;
+    const f32x4 s2 = *reinterpret_cast<const f32x4*>(coeff2 + 2 * C + c);
+    const f32x4 h2c = *reinterpret_cast<const f32x4*>(coeff2 + 3 * C + c);
+    const f32x4 ss = *reinterpret_cast<const f32x4*>(coeffs + 2 * C + c);
+    const f32x4 hs = *reinterpret_cast<const f32x4*>(coeffs + 3 * C + c);
+    f32x4 m = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = fmaf(fmaf(a[q][k][e], s2[e], h2c[e]), gs[c + e], fmaf(s[q][k][e], ss[e], hs[e]));
+        m[e] = fmaxf(m[e], z);
+      }
+    *reinterpret_cast<f32x4*>(out + ((long)b * per_utt + idx[q]) * 4) = m;
   }
 }
 
@@ -571,6 +639,42 @@ __global__ __launch_bounds__(256) void res_gate_relu_pool_mean_kernel(const floa
   const int H2 = H / 2, W2 = W / 2, P2 = H2 * W2;
   const float s2 = coeff2[2 * C + c], h2c = coeff2[3 * C + c], ss = coeffs[2 * C + c], hs = coeffs[3 * C + c];
   const float gt = gate[(long)b * C + c];
+  float acc = 0.f;
+  for (int p2 = w; p2 < P2; p2 += 4) {
+    const int h2 = p2 / W2, w2 = p2 - h2 * W2;
+    float a[4], s[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long off = (((long)b * H + 2 * h2 + (k >> 1)) * W + 2 * w2 + (k & 1)) * C + c;
+      a[k] = c2[off];
+      s[k] = sc[off];
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m = fmaxf(m, fmaf(fmaf(a[k], s2, h2c), gt, fmaf(s[k], ss, hs)));
+    acc += m;
+  }
+  part[w][lane] = acc;
+  __syncthreads();
+  if (w == 0) feat[(long)b * C + c] = (((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane]) / (float)P2;
+}
+
+// res_gate_relu_pool_mean_kernel with the squeeze-excite gate worked out by every workgroup for its utterance (see
+// res_segate_relu_pool_kernel); the workgroup of the first 64 channels stores gap / hid / gate.
+__global__ __launch_bounds__(256) void res_segate_relu_pool_mean_kernel(
+    const float* __restrict__ c2, const float* __restrict__ sc, const float* __restrict__ coeff2,
+    const float* __restrict__ coeffs, const float* __restrict__ bsum, const float* __restrict__ fc1,
+    const float* __restrict__ fc2, float inv_hw, float* __restrict__ gap, float* __restrict__ hid,
+    float* __restrict__ gate, float* __restrict__ feat, int H, int W, int C, int Ch) {
+  __shared__ float g[256], gs[256];
+  __shared__ float hd[16];
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
+  const int H2 = H / 2, W2 = W / 2, P2 = H2 * W2;
+  const float s2 = coeff2[2 * C + c], h2c = coeff2[3 * C + c], ss = coeffs[2 * C + c], hs = coeffs[3 * C + c];
+  se_gate_body(bsum, coeff2, fc1, fc2, inv_hw, gap, hid, gate, b, C, Ch, blockIdx.x == 0, g, hd, gs);
+  const float gt = gs[c];
   float acc = 0.f;
   for (int p2 = w; p2 < P2; p2 += 4) {
     const int h2 = p2 / W2, w2 = p2 - h2 * W2;
@@ -1167,6 +1271,29 @@ MMSA_EXPORT int mmsa_res_gate_relu_pool_mean(const float* c2, const float* sc, c
   MMSA_REQUIRE(C >= 64 && C % 64 == 0);
   hipLaunchKernelGGL(res_gate_relu_pool_mean_kernel, dim3(C / 64, B), dim3(256), 0, mmsa_stream(stream), c2, sc, coeff2,
                      coeffs, gate, feat, H, W, C);
+  return mmsa_launch_status();
+}
+
+// mmsa_se_gate followed by mmsa_res_gate_relu_pool (feat == null: out [B][H/2][W/2][C]) or by
+// mmsa_res_gate_relu_pool_mean (out == null: feat [B][C]) in one launch: the same values bit for bit, gap / hid / gate
+// stored as mmsa_se_gate stores them.
+MMSA_EXPORT int mmsa_res_se_gate_relu_pool(const float* c2, const float* sc, const float* coeff2, const float* coeffs,
+                                           const float* bsum, const float* W1, const float* W2, float* gap, float* hid,
+                                           float* gate, float* out, float* feat, int B, int H, int W, int C, int Ch,
+                                           void* stream) {
+  MMSA_REQUIRE(c2 && sc && coeff2 && coeffs && bsum && W1 && W2 && gap && hid && gate && (out != nullptr) != (feat != nullptr));
+  MMSA_REQUIRE(B > 0 && B <= 65535 && H >= 2 && W >= 2 && C > 0 && C <= 256 && C % 4 == 0 && Ch > 0 && Ch <= 16);
+  const float inv_hw = 1.0f / (float)(H * W);
+  if (feat) {
+    MMSA_REQUIRE(C % 64 == 0);
+    hipLaunchKernelGGL(res_segate_relu_pool_mean_kernel, dim3(C / 64, B), dim3(256), 0, mmsa_stream(stream), c2, sc,
+                       coeff2, coeffs, bsum, W1, W2, inv_hw, gap, hid, gate, feat, H, W, C, Ch);
+  } else {
+    const int per_utt = (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(res_segate_relu_pool_kernel, dim3(mmsa_cdiv(per_utt, 256 * SEPOOL_QUADS), B), dim3(256), 0,
+                       mmsa_stream(stream), c2, sc, coeff2, coeffs, bsum, W1, W2, inv_hw, gap, hid, gate, out, H, W, C,
+                       Ch);
+  }
   return mmsa_launch_status();
 }
 

@@ -26,6 +26,8 @@ FUSE_BN_BWD_STATS = _os.environ.get("MMSA_FUSE_BN_BWD_STATS", "1") != "0"
 # 0: the global average pool behind the last block (and its backward) as launches of their own instead of inside the
 # block's pooling kernel / its backward (A/B aid)
 FUSE_GAP = _os.environ.get("MMSA_FUSE_GAP", "1") != "0"
+# 1: the squeeze-excite gate inside the pooling kernel that consumes it (0: a launch of its own; A/B aid)
+FUSE_SE_GATE = _os.environ.get("MMSA_FUSE_SE_GATE", "1") != "0"
 # 1: a block's first 3x3 convolution and its 1x1 shortcut share one launch (and one BatchNorm coefficient launch)
 FWD_PAIR = _os.environ.get("MMSA_FWD_PAIR", "1") != "0"
 # 1: inference folds bn1 + ReLU into the epilogue of a block's first convolution (0: separate pass, as in training)
@@ -202,16 +204,26 @@ def block_forward(blk, name, a_in, B, H, W, Cin, Cout, training, need_grad, ws: 
     s.gap = ws.buf(name + ".gap", (B, Cout))
     s.hid = ws.buf(name + ".hid", (B, Ch))
     s.gate = ws.buf(name + ".gate", (B, Cout))
-    ops.se_gate(s.bsum2, s.coeff2, W1, W2, H * W, s.gap, s.hid, s.gate, B, Cout)
+    fused_gate = FUSE_SE_GATE and Cout <= 256 and Ch <= 16 and (mean_out is None or Cout % 64 == 0)
+    if not fused_gate:
+        ops.se_gate(s.bsum2, s.coeff2, W1, W2, H * W, s.gap, s.hid, s.gate, B, Cout)
     if fsc is not None:
         fsc.join()
     if mean_out is not None:
         # the branch's last block: only the mean of its pooled output is wanted (the global average pool follows)
         s.out = None
-        ops.res_gate_relu_pool_mean(s.c2, s.sc, s.coeff2, s.coeffs, s.gate, mean_out, B, H, W, Cout)
+        if fused_gate:
+            ops.res_se_gate_relu_pool(s.c2, s.sc, s.coeff2, s.coeffs, s.bsum2, W1, W2, s.gap, s.hid, s.gate, None,
+                                      mean_out, B, H, W, Cout)
+        else:
+            ops.res_gate_relu_pool_mean(s.c2, s.sc, s.coeff2, s.coeffs, s.gate, mean_out, B, H, W, Cout)
         return s
     s.out = ws.buf(name + ".out", (B, H // 2, W // 2, Cout))
-    ops.res_gate_relu_pool(s.c2, s.sc, s.coeff2, s.coeffs, s.gate, s.out, B, H, W, Cout)
+    if fused_gate:
+        ops.res_se_gate_relu_pool(s.c2, s.sc, s.coeff2, s.coeffs, s.bsum2, W1, W2, s.gap, s.hid, s.gate, s.out, None,
+                                  B, H, W, Cout)
+    else:
+        ops.res_gate_relu_pool(s.c2, s.sc, s.coeff2, s.coeffs, s.gate, s.out, B, H, W, Cout)
     return s
 
 

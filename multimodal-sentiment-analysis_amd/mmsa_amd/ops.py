@@ -541,6 +541,20 @@ def res_gate_relu_pool_mean(c2, sc, coeff2, coeffs, gate, feat, B, H, W, C):
               B, H, W, C, _stream())
 
 
+def res_se_gate_relu_pool(c2, sc, coeff2, coeffs, bsum, W1, W2, gap, hid, gate, out, feat, B, H, W, C):
+    """:func:`se_gate` and the pooling that consumes its gate in one launch: into ``out`` [B, H/2, W/2, C]
+    (:func:`res_gate_relu_pool`) or, with ``out`` None, into ``feat`` [B, C] (:func:`res_gate_relu_pool_mean`)."""
+    Ch = W1.shape[0]
+    n = B * H * W * C
+    if (c2.numel() != n or sc.numel() != n or W1.numel() != Ch * C or W2.numel() != C * Ch or bsum.numel() != B * C
+            or gate.numel() != B * C or gap.numel() != B * C or hid.numel() != B * Ch or (out is None) == (feat is None)
+            or (out is not None and out.numel() != B * (H // 2) * (W // 2) * C)
+            or (feat is not None and feat.numel() != B * C)):
+        raise ValueError("res_se_gate_relu_pool: bad sizes")
+    _lib.call("mmsa_res_se_gate_relu_pool", _chk(c2), _chk(sc), _chk(coeff2), _chk(coeffs), _chk(bsum), _chk(W1),
+              _chk(W2), _chk(gap), _chk(hid), _chk(gate), _opt(out), _opt(feat), B, H, W, C, Ch, _stream())
+
+
 def gate_affine_add(a, coeff2, gate, sc, coeffs, out, B, P, C, relu: bool):
     """out = [relu]((a * scale2 + shift2) * gate + (sc * scale_s + shift_s)) over [B, P, C] maps; coefficient tables,
     gate and second map are optional (identity / 1 / 0)."""

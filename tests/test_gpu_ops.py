@@ -681,3 +681,36 @@ def test_weight_gradient_slabs_match_float64(B, H, W, Cin, Cout, sc):
         w1 = torch.zeros(Cout, Cin, 1, 1, dtype=torch.float64, requires_grad=True)
         F.conv2d(xd, w1).backward(dy1.permute(0, 3, 1, 2).double())
         assert float((dW1.cpu().double() - w1.grad).abs().max()) < 2e-5 * float(w1.grad.abs().max())
+
+
+@pytest.mark.parametrize("B,H,W,C,mean", [(3, 32, 65, 64, False), (5, 16, 32, 128, False), (2, 7, 19, 64, False),
+                                          (4, 8, 16, 256, True), (33, 8, 16, 256, False), (3, 6, 10, 64, True)])
+def test_squeeze_excite_gate_inside_the_pooling_launch(B, H, W, C, mean):
+    """The gate worked out by every workgroup of the pooling launch for its utterance against the separate gate launch
+    followed by the pooling launch: pooled map (or its mean), gap, hidden units and gate bit for bit."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(C + W)
+    Ch = C // 16
+    c2 = torch.randn(B, H, W, C, generator=g, device=DEV)
+    sc = torch.randn(B, H, W, C, generator=g, device=DEV)
+    coeff2 = torch.randn(4, C, generator=g, device=DEV)
+    coeffs = torch.randn(4, C, generator=g, device=DEV)
+    bsum = torch.randn(B, C, generator=g, device=DEV) * H * W
+    W1 = torch.randn(Ch, C, generator=g, device=DEV) * 0.2
+    W2 = torch.randn(C, Ch, generator=g, device=DEV) * 0.5
+    ref = [torch.empty(B, C, device=DEV), torch.empty(B, Ch, device=DEV), torch.empty(B, C, device=DEV)]
+    ops.se_gate(bsum, coeff2, W1, W2, H * W, ref[0], ref[1], ref[2], B, C)
+    got = [torch.full_like(t, float("nan")) for t in ref]
+    if mean:
+        want = torch.empty(B, C, device=DEV)
+        ops.res_gate_relu_pool_mean(c2, sc, coeff2, coeffs, ref[2], want, B, H, W, C)
+        out = torch.full_like(want, float("nan"))
+        ops.res_se_gate_relu_pool(c2, sc, coeff2, coeffs, bsum, W1, W2, got[0], got[1], got[2], None, out, B, H, W, C)
+    else:
+        want = torch.empty(B, H // 2, W // 2, C, device=DEV)
+        ops.res_gate_relu_pool(c2, sc, coeff2, coeffs, ref[2], want, B, H, W, C)
+        out = torch.full_like(want, float("nan"))
+        ops.res_se_gate_relu_pool(c2, sc, coeff2, coeffs, bsum, W1, W2, got[0], got[1], got[2], out, None, B, H, W, C)
+    assert torch.equal(out, want)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
