@@ -437,6 +437,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const ReduceDes
   if (i < total) {
     const float* src = d.slabs + i;
     int k = w;
+    f32x4 t0 = zero, t1 = zero, t2 = zero, t3 = zero;
+    for (; k + 28 < d.nslabs; k += 32) {          // eight 16-byte loads in flight per lane
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(src + (long)k * total);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + (long)(k + 4) * total);
+      const f32x4 a2 = *reinterpret_cast<const f32x4*>(src + (long)(k + 8) * total);
+      const f32x4 a3 = *reinterpret_cast<const f32x4*>(src + (long)(k + 12) * total);
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(src + (long)(k + 16) * total);
+      const f32x4 a5 = *reinterpret_cast<const f32x4*>(src + (long)(k + 20) * total);
+      const f32x4 a6 = *reinterpret_cast<const f32x4*>(src + (long)(k + 24) * total);
+      const f32x4 a7 = *reinterpret_cast<const f32x4*>(src + (long)(k + 28) * total);
+      s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+      t0 += a4; t1 += a5; t2 += a6; t3 += a7;
+    }
+    s0 += t0; s1 += t1; s2 += t2; s3 += t3;
     for (; k + 12 < d.nslabs; k += 16) {
       s0 += *reinterpret_cast<const f32x4*>(src + (long)k * total);
       s1 += *reinterpret_cast<const f32x4*>(src + (long)(k + 4) * total);
