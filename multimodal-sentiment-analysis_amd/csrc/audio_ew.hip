@@ -310,7 +310,8 @@ __global__ __launch_bounds__(256) void stem_bwd_w_kernel(const float* __restrict
 }
 
 // sum partial[rows][320] (c*10+k) -> dW[32*9], dbias[32].  16 columns per workgroup of 256 threads: lane group
-// t >> 4 takes every sixteenth row (four loads in flight), the sixteen groups are added in fixed order.
+// t >> 4 takes every sixteenth row (sixteen loads in flight: the kernel is a chain of round trips on the step's
+// tail), the sixteen groups are added in fixed order.
 __global__ __launch_bounds__(256) void stem_bwd_w_finalize_kernel(const float* __restrict__ partial, int rows,
                                                                   float* __restrict__ dW, float* __restrict__ db) {
   __shared__ double red[16][16];
@@ -319,6 +320,15 @@ __global__ __launch_bounds__(256) void stem_bwd_w_finalize_kernel(const float* _
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (col < 320) {
     int r = rg;
+    for (; r + 240 < rows; r += 256) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = partial[(long)(r + 16 * u) * 320 + col];
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        s0 += (double)v[u]; s1 += (double)v[u + 1]; s2 += (double)v[u + 2]; s3 += (double)v[u + 3];
+      }
+    }
     for (; r + 48 < rows; r += 64) {
       s0 += (double)partial[(long)r * 320 + col];
       s1 += (double)partial[(long)(r + 16) * 320 + col];
