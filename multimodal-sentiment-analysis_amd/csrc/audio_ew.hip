@@ -880,7 +880,19 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ p
   const int b = blockIdx.x, t = threadIdx.x;
   if (t < C) {
     float a[3] = {0.f, 0.f, 0.f};
-    for (int k = 0; k < nchunks; ++k)
+    int k = 0;
+    for (; k + 4 <= nchunks; k += 4) {       // twelve loads in flight; the sums keep their order
+      float v[4][3];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[u][j] = partial[(((long)b * nchunks + k + u) * 3 + j) * C + t];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) a[j] += v[u][j];
+    }
+    for (; k < nchunks; ++k)
 #pragma unroll
       for (int j = 0; j < 3; ++j) a[j] += partial[(((long)b * nchunks + k) * 3 + j) * C + t];
 #pragma unroll
