@@ -1344,9 +1344,18 @@ MMSA_EXPORT int mmsa_gap_bwd(const float* dout, float* dx, int B, int P, int C, 
 }
 
 // Scratch floats needed by mmsa_resblock_bwd_ew for a given geometry.
+// Pooled positions per workgroup of the element-wise backward's first pass: up to four per position lane, fewer while
+// the launch would have under 512 workgroups (the small maps of the last blocks: a workgroup's passes are a chain of
+// round trips, and 64 workgroups leave three quarters of the CUs idle).
+static int rb_bwd_chunk(int B, int P2, int planes) {
+  int passes = 4;
+  while (passes > 1 && (long)B * ((P2 + planes * passes - 1) / (planes * passes)) < 512) passes >>= 1;
+  return planes * passes;
+}
+
 MMSA_EXPORT long mmsa_resblock_bwd_scratch_floats(int B, int H, int W, int C) {
   if (B <= 0 || H < 2 || W < 2 || C < 64 || C > 256 || C % 64) return MMSA_ERR_ARG;
-  const int planes = 1024 / C, chunk = planes * 4;
+  const int planes = 1024 / C, chunk = rb_bwd_chunk(B, (H / 2) * (W / 2), planes);
   const int P2 = (H / 2) * (W / 2);
   const int nchunks = (P2 + chunk - 1) / chunk;
   const int Ch = C / 16;
@@ -1366,7 +1375,7 @@ static int resblock_bwd_ew_impl(const float* dout, int dout_mean, const float* c
   MMSA_REQUIRE(dgamma2 && dbeta2 && dgammas && dbetas && scratch && (dW1 != nullptr) == (dW2 != nullptr));
   MMSA_REQUIRE(B > 0 && H >= 2 && W >= 2 && C >= 64 && C <= 256 && C % 64 == 0);
   hipStream_t s = mmsa_stream(stream);
-  const int planes = 1024 / C, chunk = planes * 4;
+  const int planes = 1024 / C, chunk = rb_bwd_chunk(B, (H / 2) * (W / 2), planes);
   const int P2 = (H / 2) * (W / 2);
   const int nchunks = (P2 + chunk - 1) / chunk;
   const int Ch = C / 16;
@@ -1422,7 +1431,7 @@ MMSA_EXPORT int mmsa_resblock_bwd_se_wgrad(const float* scratch, const float* hi
                                            float* dW2, int B, int H, int W, int C, void* stream) {
   MMSA_REQUIRE(scratch && hid && gap && dW1 && dW2);
   MMSA_REQUIRE(B > 0 && H >= 2 && W >= 2 && C >= 64 && C <= 256 && C % 64 == 0);
-  const int planes = 1024 / C, chunk = planes * 4;
+  const int planes = 1024 / C, chunk = rb_bwd_chunk(B, (H / 2) * (W / 2), planes);
   const int P2 = (H / 2) * (W / 2);
   const int nchunks = (P2 + chunk - 1) / chunk;
   const int Ch = C / 16;
