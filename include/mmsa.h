@@ -261,13 +261,17 @@ MMSA_API int mmsa_bias_relu_maxtime_multi(const float* const* y_host, const floa
                                           const int* Lout_host, int n, float* feat, int* arg, int B, int L, int F,
                                           int ldf, void* stream);
 /* sparse backward of conv + ReLU + max over time + gather; ksize/feat_off/wp/dW/dbias are host arrays
- * (wp/dW/dbias: host arrays of device pointers); dtable [vocab][E] is accumulated into; rows == padding_idx get
- * nothing; tokens outside [0, vocab) write nothing and set *err (optional device int) to 1, where the reference's
- * nn.Embedding raises IndexError */
+ * (wp/dW/dbias: host arrays of device pointers); dtable [vocab][E]: the rows of the batch's tokens are overwritten
+ * (the caller clears the table beforehand); rows == padding_idx get nothing; tokens outside [0, vocab) write nothing
+ * and set *err (optional device int) to 1, where the reference's nn.Embedding raises IndexError.  A token that
+ * occurs several times in the batch has its rows summed in ascending position, as the reference's CPU
+ * embedding backward does: the result is the same bits on every run.  Workspaces: drow B*L*E floats, groups
+ * 5*B*L ints, id_table 2*vocab ints (zero before the first call; every call leaves them zero again) */
 MMSA_API int mmsa_text_bwd(const float* dfeat, const float* feat, const int* arg, const float* emb,
                            const long long* ids, int nconv, const int* ksize_host, const int* feat_off_host,
                            const float* const* wp_host, float* const* dW_host, float* const* dbias_host, float* dtable,
-                           int B, int L, int E, int F, int ldf, long padding_idx, long vocab, int* err, void* stream);
+                           float* drow, int* groups, int* id_table, int B, int L, int E, int F, int ldf,
+                           long padding_idx, long vocab, int* err, void* stream);
 
 /* ---- fusion head and classifiers: multimodal_model.py:202-225, :228-285, :365-404, :448-454. ---------------- */
 MMSA_API int mmsa_dense_fwd(const float* X, int ldx, const float* W, const float* bias, const float* gamma,

@@ -120,19 +120,88 @@ struct TextConvs {
   const float* wp[4];  // packed [j][F][E]
 };
 
+// Groups the token positions of a batch by token id, so that the gradients of a token that occurs several times
+// can be summed in a fixed order (ascending position) instead of meeting in float atomics in arrival order.
+// One workgroup; thread i owns positions i, i + 1024, ... in every phase.
+//   table [vocab][2] ints, all zero between launches (the kernel clears what it touched): running count | segment start
+//   work  [5][ntok] ints: arrival index | unsorted members | seg_cnt | seg_off | members
+// Result: for the FIRST position p of every distinct valid id, seg_cnt[p] = number of positions holding that id and
+// members[seg_off[p] .. + seg_cnt[p]) = those positions in ascending order; seg_cnt = 0 at every other position.
+// Padding tokens and ids outside the table belong to no group.  The arrival order of the counting atomics and the
+// placement of the segments vary from run to run; the sorted segments and seg_cnt do not.
+__device__ __forceinline__ int coherent_load(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(1024) void token_groups_kernel(const long long* __restrict__ ids, long ntok, long vocab,
+                                                            long padding_idx, int* table, int* work) {
+  __shared__ int total;
+  int* arrival = work;
+  int* unsorted = work + ntok;
+  int* seg_cnt = work + 2 * ntok;
+  int* seg_off = work + 3 * ntok;
+  int* members = work + 4 * ntok;
+  const int tid = threadIdx.x;
+  if (tid == 0) total = 0;
+  for (long p = tid; p < ntok; p += 1024) {
+    const long long id = ids[p];
+    const bool valid = id >= 0 && id < vocab && id != padding_idx;
+    arrival[p] = valid ? atomicAdd(table + 2 * id, 1) : -1;
+    seg_cnt[p] = 0;
+  }
+  __syncthreads();
+  for (long p = tid; p < ntok; p += 1024) {      // whoever arrived first reserves the id's segment
+    if (arrival[p] != 0) continue;
+    int* e = table + 2 * ids[p];
+    const int c = coherent_load(e);
+    __hip_atomic_store(e + 1, atomicAdd(&total, c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  for (long p = tid; p < ntok; p += 1024) {
+    const int a = arrival[p];
+    if (a < 0) continue;
+    const int off = coherent_load(table + 2 * ids[p] + 1);
+    __hip_atomic_store(unsorted + off + a, (int)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  for (long p = tid; p < ntok; p += 1024) {      // rank of p among the positions of its id
+    if (arrival[p] < 0) continue;
+    const int* e = table + 2 * ids[p];
+    const int c = coherent_load(e), off = coherent_load(e + 1);
+    int rank = 0;
+    for (int j = 0; j < c; ++j) rank += coherent_load(unsorted + off + j) < (int)p;
+    members[off + rank] = (int)p;
+    arrival[p] = rank;
+    if (rank == 0) {
+      seg_cnt[p] = c;
+      seg_off[p] = off;
+    }
+  }
+  __syncthreads();
+  for (long p = tid; p < ntok; p += 1024) {
+    if (arrival[p] != 0) continue;
+    int* e = table + 2 * ids[p];
+    e[0] = 0;
+    e[1] = 0;
+  }
+}
+
 // Gradient of one gathered embedding row: grid = (L, B), one row (b, t) per workgroup.
 //   dEmb[b][t][c] = sum over convs i, filters f, taps j with arg[b][i,f] + j == t of  g[b][i,f] * W_i[f][c][j]
 // Phase 1: the threads test the utterance's (conv, filter) pairs in parallel and compact the matching ones into
 // an LDS list (ballot + prefix count, so the list order is the pair order: deterministic).  Phase 2: thread c
 // walks the list four entries at a time, so four coalesced weight-row loads are in flight per step.
-// Rows of padding tokens and of tokens outside the vocabulary are skipped; the finished row is added to the table gradient with float atomics
-// (tokens repeated across the batch meet there).
+// Rows of padding tokens and of tokens outside the vocabulary are skipped.  A token that occurs once in the batch
+// stores its row straight into the table gradient; the rows of a token that occurs several times go to drow[b][t]
+// and text_sum_rows_kernel adds them up in position order.
 __global__ __launch_bounds__(256) void text_bwd_emb_kernel(const float* __restrict__ dfeat,
                                                            const float* __restrict__ feat,
                                                            const int* __restrict__ arg,
                                                            const long long* __restrict__ ids, TextConvs cv,
-                                                           float* __restrict__ dtable, int L, int E, int F, int ldf,
-                                                           long padding_idx, long vocab, int* __restrict__ err) {
+                                                           float* __restrict__ dtable, float* __restrict__ drow,
+                                                           const int* __restrict__ seg_cnt, int L, int E, int F,
+                                                           int ldf, long padding_idx, long vocab,
+                                                           int* __restrict__ err) {
   extern __shared__ float sm[];
   const int nf = cv.nconv * F;
   float* lg = sm;                                       // [nf + 4] gradient of the matching pair
@@ -140,12 +209,14 @@ __global__ __launch_bounds__(256) void text_bwd_emb_kernel(const float* __restri
   int* loff = lci + nf + 4;                             // [nf + 4] offset of the weight row inside that conv's pack
   __shared__ int wave_cnt[4];
   const int t = blockIdx.x, b = blockIdx.y;
-  const long long id = ids[(long)b * L + t];
+  const long pos = (long)b * L + t;
+  const long long id = ids[pos];
   if (id == padding_idx) return;                        // uniform: the whole block leaves
   if (id < 0 || id >= vocab) {                          // no row of the table belongs to this token: write nothing
     if (threadIdx.x == 0 && err) *err = 1;
     return;
   }
+  const bool alone = seg_cnt[pos] == 1;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int count = 0;
   for (int base = 0; base < nf; base += 256) {
@@ -185,13 +256,14 @@ __global__ __launch_bounds__(256) void text_bwd_emb_kernel(const float* __restri
     count += total;
     __syncthreads();
   }
-  if (count == 0) return;
+  if (count == 0 && alone) return;                      // the table gradient was cleared before this launch
   if (tid < 4) {                                        // pad the list to a multiple of four with null entries
     lg[count + tid] = 0.f;
     lci[count + tid] = 0;
     loff[count + tid] = 0;
   }
   __syncthreads();
+  float* dst = alone ? dtable + id * E : drow + pos * E;
   for (int c = tid; c < E; c += 256) {
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int i = 0; i < count; i += 4) {
@@ -204,7 +276,33 @@ __global__ __launch_bounds__(256) void text_bwd_emb_kernel(const float* __restri
       a2 = fmaf(lg[i + 2], w2, a2);
       a3 = fmaf(lg[i + 3], w3, a3);
     }
-    atomicAdd(dtable + id * E + c, (a0 + a1) + (a2 + a3));
+    dst[c] = (a0 + a1) + (a2 + a3);
+  }
+}
+
+// dtable[id] = drow[m_0] + drow[m_1] + ... (left to right, m ascending) for every id that occurs more than once:
+// grid = (L, B), the workgroup of the id's first position does the sum, every other one leaves at once.
+__global__ __launch_bounds__(256) void text_sum_rows_kernel(const long long* __restrict__ ids,
+                                                            const float* __restrict__ drow,
+                                                            const int* __restrict__ seg_cnt,
+                                                            const int* __restrict__ seg_off,
+                                                            const int* __restrict__ members,
+                                                            float* __restrict__ dtable, int L, int E) {
+  const long pos = (long)blockIdx.y * L + blockIdx.x;
+  const int n = seg_cnt[pos];
+  if (n < 2) return;
+  const int* m = members + seg_off[pos];
+  float* dst = dtable + ids[pos] * E;
+  for (int c = threadIdx.x; c < E; c += 256) {
+    float acc = drow[(long)m[0] * E + c];
+    int i = 1;
+    for (; i + 4 <= n; i += 4) {                        // four loads in flight, added in order
+      const float r0 = drow[(long)m[i] * E + c], r1 = drow[(long)m[i + 1] * E + c];
+      const float r2 = drow[(long)m[i + 2] * E + c], r3 = drow[(long)m[i + 3] * E + c];
+      acc = (((acc + r0) + r1) + r2) + r3;
+    }
+    for (; i < n; ++i) acc += drow[(long)m[i] * E + c];
+    dst[c] = acc;
   }
 }
 
@@ -249,15 +347,22 @@ MMSA_EXPORT int mmsa_bias_relu_maxtime_multi(const float* const* y, const float*
 
 // Backward of the whole text branch.  dfeat/feat/arg: [B][ldf] with conv i's filters at columns feat_off[i]..+F.
 // emb: gathered rows [B][L][E].  wp[i]: forward-packed weights [k_i][F][E].  dW[i]: [F][E][k_i] (overwritten),
-// dbias[i]: [F] (overwritten).  dtable: [vocab][E], ACCUMULATED into (caller zeroes it).  A token id outside
-// [0, vocab) has no row: its gradient is dropped and *err (optional) is set to 1.
+// dbias[i]: [F] (overwritten).  dtable: [vocab][E]: the rows of the batch's tokens are overwritten, every other
+// row is left alone (the caller clears the table beforehand).  A token id outside [0, vocab) has no row: its
+// gradient is dropped and *err (optional) is set to 1.  The result does not depend on the order in which workgroups
+// run: the rows of a token that occurs several times are summed by position.  Workspaces: drow [B*L][E] floats,
+// groups 5*B*L ints, id_table 2*vocab ints that must be zero at the first call and are left zero by every call.
 MMSA_EXPORT int mmsa_text_bwd(const float* dfeat, const float* feat, const int* arg, const float* emb,
                               const long long* ids, int nconv, const int* ksize, const int* feat_off,
-                              const float* const* wp, float* const* dW, float* const* dbias, float* dtable, int B, int L,
-                              int E, int F, int ldf, long padding_idx, long vocab, int* err, void* stream) {
+                              const float* const* wp, float* const* dW, float* const* dbias, float* dtable,
+                              float* drow, int* groups, int* id_table, int B, int L, int E, int F, int ldf,
+                              long padding_idx, long vocab, int* err, void* stream) {
   MMSA_REQUIRE(dfeat && feat && arg && emb && ids && ksize && feat_off && wp && dW && dbias && dtable && vocab > 0);
+  MMSA_REQUIRE(drow && groups && id_table && (long)B * L < (1l << 30));
   MMSA_REQUIRE(nconv >= 1 && nconv <= 4 && B > 0 && B <= 65535 && L > 0 && E > 0 && E <= 1024 && E % 64 == 0 && F > 0);
   hipStream_t s = mmsa_stream(stream);
+  const long ntok = (long)B * L;
+  hipLaunchKernelGGL(token_groups_kernel, dim3(1), dim3(1024), 0, s, ids, ntok, vocab, padding_idx, id_table, groups);
   TextConvs cv;
   cv.nconv = nconv;
   for (int i = 0; i < 4; ++i) {
@@ -283,7 +388,10 @@ MMSA_EXPORT int mmsa_text_bwd(const float* dfeat, const float* feat, const int* 
   }
   const size_t shmem = (size_t)3 * (nconv * F + 4) * sizeof(float);
   MMSA_REQUIRE(shmem <= 48 * 1024);
-  hipLaunchKernelGGL(text_bwd_emb_kernel, dim3(L, B), dim3(256), shmem, s, dfeat, feat, arg, ids, cv, dtable, L, E, F,
-                     ldf, padding_idx, vocab, err);
+  const int* seg_cnt = groups + 2 * ntok;
+  hipLaunchKernelGGL(text_bwd_emb_kernel, dim3(L, B), dim3(256), shmem, s, dfeat, feat, arg, ids, cv, dtable, drow,
+                     seg_cnt, L, E, F, ldf, padding_idx, vocab, err);
+  hipLaunchKernelGGL(text_sum_rows_kernel, dim3(L, B), dim3(256), 0, s, ids, drow, seg_cnt, groups + 3 * ntok,
+                     groups + 4 * ntok, dtable, L, E);
   return mmsa_launch_status();
 }

@@ -229,7 +229,7 @@ class _BranchFn(torch.autograd.Function):
         if isinstance(m, AudioModel):
             audio_engine.audio_backward(m, ctx.st, dfeat, ctx.training, grads, ctx.ws)
         else:
-            text_engine.text_backward(m, ctx.st, dfeat, grads)
+            text_engine.text_backward(m, ctx.st, dfeat, grads, ctx.ws)
         return (None, None) + tuple(grads.get(p) for p in plist)
 
 
@@ -595,7 +595,7 @@ class MultimodalSentimentModel(nn.Module):
 
         if phase == "early":
             run.d_audio, d_t = head_engine.head_backward_both(self, run.head, dlogits, grads, ws)
-            text_engine.text_backward(self.text_model, run.text, d_t, grads)
+            text_engine.text_backward(self.text_model, run.text, d_t, grads, ws)
             side_work()
             audio_engine.fork(ws, dev, 2).join()
             return
@@ -608,7 +608,7 @@ class MultimodalSentimentModel(nn.Module):
             # launch order matters under graph replay: the short text branch and the side work are enqueued first (they
             # then start at once on helper queues), the audio chain after them
             with audio_engine.fork(ws, dev, 1) as f:
-                text_engine.text_backward(self.text_model, run.text, d_t, grads)
+                text_engine.text_backward(self.text_model, run.text, d_t, grads, ws)
             side_work()
             audio_engine.audio_backward(self.audio_model, run.audio, d_a, self.audio_model.training, grads, ws)
             f.join()
@@ -618,7 +618,7 @@ class MultimodalSentimentModel(nn.Module):
             side_work()
         else:
             d_t = head_engine.head_backward_text(self, run.head, dlogits, grads, ws)
-            text_engine.text_backward(self.text_model, run.text, d_t, grads)
+            text_engine.text_backward(self.text_model, run.text, d_t, grads, ws)
             side_work()
         audio_engine.fork(ws, dlogits.device, 2).join()      # the head's parameter gradients (helper stream 2)
 

@@ -702,7 +702,10 @@ def bias_relu_maxtime_multi(ys, biases, louts, feat, arg, B, L, F):
               _iarr(louts), n, _chk(feat), _chk(arg, torch.int32), B, L, F, n * F, _stream())
 
 
-def text_bwd(dfeat, feat, arg, emb, ids, ksizes, wps, dWs, dbs, dtable, B, L, E, F, padding_idx=0, err=None):
+def text_bwd(dfeat, feat, arg, emb, ids, ksizes, wps, dWs, dbs, dtable, B, L, E, F, padding_idx=0, err=None,
+             drow=None, groups=None, id_table=None):
+    """Workspaces (allocated here when not given): ``drow`` [B*L, E] floats, ``groups`` 5*B*L ints, ``id_table``
+    2*vocab ints that are zero before the first call (every call leaves them zero)."""
     n = len(ksizes)
     ldf = n * F
     if dfeat.shape != (B, ldf) or feat.shape != (B, ldf) or arg.shape != (B, ldf) or emb.numel() != B * L * E:
@@ -712,10 +715,19 @@ def text_bwd(dfeat, feat, arg, emb, ids, ksizes, wps, dWs, dbs, dtable, B, L, E,
             raise ValueError("text_bwd: bad weight sizes")
     if dtable.dim() != 2 or dtable.shape[1] != E:
         raise ValueError("text_bwd: dtable must be [vocab, E]")
+    if drow is None:
+        drow = torch.empty(B * L * E, dtype=F32, device=dtable.device)
+    if groups is None:
+        groups = torch.empty(5 * B * L, dtype=torch.int32, device=dtable.device)
+    if id_table is None:
+        id_table = torch.zeros(2 * dtable.shape[0], dtype=torch.int32, device=dtable.device)
+    if drow.numel() < B * L * E or groups.numel() < 5 * B * L or id_table.numel() < 2 * dtable.shape[0]:
+        raise ValueError("text_bwd: workspace too small")
     _lib.call("mmsa_text_bwd", _chk(dfeat), _chk(feat), _chk(arg, torch.int32), _chk(emb),
               _chk(ids, torch.int64), n, _iarr(ksizes), _iarr([i * F for i in range(n)]),
               _parr([_chk(w) for w in wps]), _parr([_chk(w) for w in dWs]), _parr([_chk(w) for w in dbs]),
-              _chk(dtable), B, L, E, F, ldf, padding_idx, dtable.shape[0], _opt(err, torch.int32), _stream())
+              _chk(dtable), _chk(drow), _chk(groups, torch.int32), _chk(id_table, torch.int32), B, L, E, F, ldf,
+              padding_idx, dtable.shape[0], _opt(err, torch.int32), _stream())
 
 
 # ---------------------------------------------------------------------------------------------- dense head

@@ -72,12 +72,16 @@ def check_ids_host(input_ids: torch.Tensor, vocab: int):
         raise IndexError("index out of range in self")
 
 
-def text_backward(m, st, dfeat: torch.Tensor, grads: Grads):
+def text_backward(m, st, dfeat: torch.Tensor, grads: Grads, ws: Workspace):
     table = m.embedding.weight
     dtable = grads.of(table)
     if not getattr(st, "dtable_zeroed", False):
-        dtable.zero_()    # the kernel scatter-adds token rows into it
+        dtable.zero_()    # the kernels write the rows of this batch's tokens only
+    ntok = st.B * st.L
+    # zero once (a persistent workspace creates it zeroed): every launch leaves it zero again
+    id_table = ws.buf("text.id_table", 2 * table.shape[0], torch.int32, zero=not ws.persistent)
     ops.text_bwd(dfeat.contiguous(), st.feat, st.arg, st.emb, st.ids, st.ksizes, st.wps,
                  [grads.of(c.weight) for c in m.convs], [grads.of(c.bias) for c in m.convs], dtable,
                  st.B, st.L, st.E, st.F, padding_idx=m.embedding.padding_idx if m.embedding.padding_idx is not None else -1,
-                 err=st.err)
+                 err=st.err, drow=ws.buf("text.drow", (ntok, st.E)), groups=ws.buf("text.groups", 5 * ntok, torch.int32),
+                 id_table=id_table)

@@ -379,6 +379,57 @@ def test_text_conv_relu_maxtime():
     assert torch.equal(arg.cpu().long()[pos], ra[pos])
 
 
+@pytest.mark.parametrize("V", [3, 50, 1000])
+def test_repeated_tokens_gradients_are_summed_in_position_order(V):
+    """Embedding backward (autograd of multimodal_model.py:179-197): the table gradient is the same bits on every run,
+    a token that occurs several times gets its rows added left to right in ascending position, the whole table agrees
+    with float64 autograd, and the id table of the grouping kernel is left zero."""
+    from mmsa_amd import text as text_engine
+    from mmsa_amd.model import TextModel
+    from mmsa_amd.workspace import Grads, Workspace
+    torch.manual_seed(3)
+    B, L, E = 16, 128, 256
+    tm = TextModel(vocab_size=V).to(DEV)
+    ids = torch.randint(0, V, (B, L), device=DEV)
+    ids[:, 100:] = 0                      # padding tail
+    ids[3, 5], ids[9, 0] = V + 7, -2      # outside the table: members of no group
+    dfeat = torch.randn(B, 384, device=DEV)
+    ws = Workspace(DEV, persistent=True)
+    tables = []
+    for _ in range(3):
+        _, st = text_engine.text_forward(tm, ids, True, ws)
+        grads = Grads()
+        text_engine.text_backward(tm, st, dfeat, grads, ws)
+        tables.append(grads.of(tm.embedding.weight).clone())
+        assert int(ws.buf("text.id_table", 2 * V, torch.int32).abs().sum()) == 0
+    st.err.zero_()
+    assert torch.equal(tables[0], tables[1]) and torch.equal(tables[0], tables[2])
+    drow = ws.buf("text.drow", (B * L, E)).cpu()
+    flat = ids.flatten().cpu()
+    got = tables[0].cpu()
+    checked = 0
+    for v in range(1, V):
+        pos = (flat == v).nonzero().flatten().tolist()
+        if len(pos) < 2:
+            continue
+        acc = drow[pos[0]].clone()
+        for p in pos[1:]:
+            acc = acc + drow[p]
+        assert torch.equal(got[v], acc), v
+        checked += 1
+    assert checked > 0 and float(got[0].abs().max()) == 0.0
+    # float64 autograd of the same graph (ids outside the table contribute nothing)
+    w64 = tm.embedding.weight.detach().cpu().double().requires_grad_(True)
+    safe = torch.where((ids >= 0) & (ids < V), ids, torch.zeros_like(ids)).cpu()
+    x = F.embedding(safe, w64, padding_idx=0)
+    bad = ((ids < 0) | (ids >= V)).cpu()
+    x = torch.where(bad[..., None], torch.zeros_like(x), x).transpose(1, 2)
+    feats = [F.relu(F.conv1d(x, c.weight.detach().cpu().double(), c.bias.detach().cpu().double())).max(dim=2)[0]
+             for c in tm.convs]
+    (torch.cat(feats, 1) * dfeat.cpu().double()).sum().backward()
+    check(got, w64.grad, 2e-5)
+
+
 # ------------------------------------------------------------------------------------------------ augmentation
 def test_batched_augmentation_matches_oracle_draw_for_draw():
     """Same `random` seed -> the GPU batch path and the oracle's utterance-by-utterance restatement of

@@ -71,19 +71,20 @@ def test_loss_curve_100_steps_matches_reference(golden):
     Bars: the first five steps agree to 2e-4.  Over 100 steps two fp32 runs of this network separate chaotically (Adam
     normalises noise-level gradients to +-lr, max-pool near-ties reroute gradients): the CPU oracle itself -- the same
     torch CPU ops as the reference, only the AdamW arithmetic written out by hand -- deviates from the recording by
-    up to 1.3e-2 (mean 1.8e-3; series "oracle_cpu_fp32" of tests/golden/loss_curve_sensitivity.json).  The HIP curve
-    is held to 4x that series' maximum and 3x its mean.  Measured with two generations of the weight-gradient
-    kernels, both within 2e-5 of float64 on every layer: max 1.9e-2 / mean 3.5e-3 and max 3.2e-2 / mean 3.9e-3 (both
-    maxima at step 69, where the recorded curve has a spike) -- where the trajectories separate is decided by
-    last-bit differences, and the curve also differs from run to run with the order of the float atomic adds that
-    scatter repeated tokens' gradients, so the free-running bar cannot be tighter than that spread.  A per-step bound that is free of this accumulation
-    is asserted by test_teacher_forced_100_steps below."""
+    up to 1.3e-2 (mean 1.8e-3; series "oracle_cpu_fp32" of tests/golden/loss_curve_sensitivity.json), and by 2.6e-2
+    (mean 4.0e-3) with oneDNN switched off (series "oracle_cpu_fp32_onednn_off").  The HIP curve is held to 2x the
+    first series' maximum and 2.5x its mean, and must lie inside the band the two CPU series span (no further from the
+    recording than the farther CPU evaluation, plus a quarter).  The step is bit-reproducible, so the curve is one fixed
+    sample per build of the kernels, but where the trajectories separate is decided by last-bit differences: six
+    generations of the kernels gave max 1.1e-2 .. 3.2e-2 and mean 2.8e-3 .. 3.9e-3 (this one: 2.3e-2 / 3.7e-3).  A
+    per-step bound that is free of this accumulation is asserted by test_teacher_forced_100_steps below."""
     import json
     from conftest import GOLDEN
     from mmsa_amd.trainer import TrainStep
     ref = golden["loss_curves"]["both"]
     with open(os.path.join(GOLDEN, "loss_curve_sensitivity.json")) as f:
-        cpu = np.array(json.load(f)["deviation"]["oracle_cpu_fp32"])
+        series = json.load(f)["deviation"]
+    cpu, cpu_off = np.array(series["oracle_cpu_fp32"]), np.array(series["oracle_cpu_fp32_onednn_off"])
     m = seeded_model("both").to(DEV).train()      # seed 42: the host RNG now sits where the reference's did
     ts = TrainStep(m, lr=1e-3, weight_decay=1e-4, max_norm=1.0)
     losses = []
@@ -100,8 +101,9 @@ def test_loss_curve_100_steps_matches_reference(golden):
     print(f"loss-curve deviation: first5 max {err[:5].max():.2e}, overall max {err.max():.2e} at step "
           f"{int(err.argmax())}, mean {err.mean():.2e}; CPU oracle vs recording: max {cpu.max():.2e} mean {cpu.mean():.2e}")
     assert err[:5].max() < 2e-4
-    assert err.max() < 4 * cpu.max(), f"max loss deviation {err.max():.2e} at step {int(err.argmax())}"
-    assert err.mean() < 3 * cpu.mean()
+    assert err.max() < 2 * cpu.max(), f"max loss deviation {err.max():.2e} at step {int(err.argmax())}"
+    assert err.mean() < 2.5 * cpu.mean()
+    assert err.max() < 1.25 * max(cpu.max(), cpu_off.max()) and err.mean() < 1.25 * max(cpu.mean(), cpu_off.mean())
     assert abs(got[-10:].mean() - want[-10:].mean()) < 2 * cpu.max()
     m.eval()
     b = batch_tensors(100000, 32, device=DEV)
@@ -120,9 +122,10 @@ def test_teacher_forced_100_steps(golden):
         double.  With the 1000-row table of test_three_steps_match_oracle the same comparison holds to 1e-5,
       * global gradient norm within 1e-4 relative,
       * the update p_after - p_before of every parameter tensor: relative L2 error against the oracle's update.
-    The update bar is 1e-3 for the median tensor of a step and 2e-2 for the worst tensor from step 10 on; in the
-    first steps Adam's v is still ~g^2, so the update of an element is ~+-lr*sign(g) and elements whose gradient is
-    rounding noise take different signs in any two fp32 implementations (bounded there by 0.2).  Tensors whose
+    The update bar is 1e-4 for the median tensor of a step (measured 3.0e-5) and 1.2e-2 for the worst tensor from
+    step 10 on (measured 5.8e-3); in the first steps Adam's v is still ~g^2, so the update of an element is
+    ~+-lr*sign(g) and elements whose gradient is rounding noise take different signs in any two fp32
+    implementations (measured 2.7e-2, bounded there by 6e-2).  Tensors whose
     true gradient is identically zero (a bias in front of a BatchNorm) are pure noise and skipped."""
     from mmsa_amd.trainer import TrainStep
     ref = golden["loss_curves"]["both"]
@@ -173,9 +176,9 @@ def test_teacher_forced_100_steps(golden):
           f"{a['update_worst'][10:].max():.2e} (steps 10-99, {rec['worst_tensor'][10 + int(a['update_worst'][10:].argmax())]})")
     assert a["loss_err"].max() < 2e-4
     assert a["gnorm_rel_err"].max() < 1e-4
-    assert a["update_median"].max() < 1e-3
-    assert a["update_worst"][:10].max() < 0.2
-    assert a["update_worst"][10:].max() < 2e-2
+    assert a["update_median"].max() < 1e-4
+    assert a["update_worst"][:10].max() < 6e-2
+    assert a["update_worst"][10:].max() < 1.2e-2
     # every HIP step was within 2e-4 of an oracle step that started from the same state; the oracle's steps trace the
     # recorded reference curve (it free-runs here), so the recording is met to 1e-3 for as long as the oracle meets it
     # (how long depends on the host: the oracle's own rounding changes with the CPU's thread count -- 12 steps with 8
@@ -185,7 +188,8 @@ def test_teacher_forced_100_steps(golden):
 
 
 def test_graph_replay_equals_eager():
-    """The captured HIP graph of the whole step must reproduce the eager launch sequence bit for bit."""
+    """The captured HIP graph of the whole step must reproduce the eager launch sequence bit for bit, over all six
+    steps (four of them replays)."""
     from mmsa_amd.trainer import TrainStep
     res = []
     for use_graph in (False, True):
@@ -196,15 +200,28 @@ def test_graph_replay_equals_eager():
             b = batch_tensors(8 * s, 8, vocab=SMALL_VOCAB, device=DEV)
             ls.append(ts.step(**_step_inputs("both", b)).clone())
         res.append((torch.stack(ls).cpu(), m._arena.flat.clone().cpu()))
-    # same kernels, same order; the only run-to-run freedom is the order of the float atomic adds that scatter
-    # repeated tokens' embedding gradients, so agreement is to rounding, not bitwise
-    # (Adam then turns a last-bit difference in a noise-level gradient into a different +-lr step for that element, and
-    # the difference grows 5-25x per step: measured between two runs of one configuration up to 1.5e-4 in the sixth
-    # loss.  The first three steps are held to rounding, the rest to a bound on that drift.)
-    dl = (res[0][0] - res[1][0]).abs().flatten()
-    assert float(dl[:3].max()) < 2e-6 and float(dl.max()) < 1e-3, dl
-    diff = float(torch.linalg.vector_norm(res[0][1] - res[1][1]))
-    assert diff < 3e-3 * float(torch.linalg.vector_norm(res[0][1])), diff
+    # same kernels, same order, and no sum in the step depends on the order in which workgroups run: bitwise
+    assert torch.equal(res[0][0], res[1][0]), (res[0][0] - res[1][0]).abs().flatten()
+    assert torch.equal(res[0][1], res[1][1])
+
+
+def test_train_step_is_bit_reproducible():
+    """Two runs of the metric's configuration (B=32, full vocabulary, the training driver's dropout defaults, graph
+    replay, [CLS]/[SEP]/repeated word ids in every utterance) end in the same bits: losses, parameters, Adam moments."""
+    from mmsa_amd.trainer import TrainStep
+    res = []
+    for _ in range(2):
+        torch.manual_seed(42)
+        m = seeded_model("both", dropout0=False).to(DEV).train()
+        ts = TrainStep(m, use_graph=True)
+        ls = []
+        for s in range(8):
+            b = batch_tensors(32 * s, 32, device=DEV)
+            ls.append(ts.step(**_step_inputs("both", b)).clone())
+        torch.cuda.synchronize()
+        res.append((torch.stack(ls).cpu(), m._arena.flat.cpu().clone(), ts.m.cpu().clone(), ts.v.cpu().clone()))
+    for a, c in zip(res[0], res[1]):
+        assert torch.equal(a, c)
 
 
 def test_train_from_waveforms_uses_frontend():
@@ -276,12 +293,9 @@ def test_single_rank_process_group_path_equals_plain_step(overlap, monkeypatch):
         for use_graph in (True, False):
             ts, l_dist, p_dist = run(dict(use_graph=use_graph))
             assert ts.dist and ts.overlap == (overlap == "1")
-            # run-to-run freedom: the order of the float atomic adds of repeated tokens' embedding gradients,
-            # amplified by Adam over six steps (see test_graph_replay_equals_eager)
-            dl = (l_plain - l_dist).abs().flatten()
-            assert float(dl[:3].max()) < 2e-6 and float(dl.max()) < 1e-3, dl
-            diff = float(torch.linalg.vector_norm(p_plain - p_dist))
-            assert diff < 3e-3 * float(torch.linalg.vector_norm(p_plain)), diff
+            # the same kernels in the same order, cut into graphs at other places, and a one-rank sum: bitwise
+            assert torch.equal(l_plain, l_dist), (l_plain - l_dist).abs().flatten()
+            assert torch.equal(p_plain, p_dist)
     finally:
         dist.destroy_process_group()
 
@@ -333,7 +347,7 @@ def test_token_id_outside_the_table_raises_and_touches_no_neighbouring_gradient(
     dtable = guard[64 * E:(64 + V) * E].view(V, E)
     dtable.zero_()
     grads = Grads({id(tm.embedding.weight): dtable})
-    text_engine.text_backward(tm, st, torch.randn(4, 384, device=DEV), grads)
+    text_engine.text_backward(tm, st, torch.randn(4, 384, device=DEV), grads, ws)
     assert bool((guard[:64 * E] == 7.0).all()) and bool((guard[(64 + V) * E:] == 7.0).all())
     assert bool(torch.isfinite(dtable).all())
     with pytest.raises(IndexError):
