@@ -56,9 +56,11 @@ MMSA_API int mmsa_logmel_fwd(const float* wave, long wave_stride, int n_valid, i
 /* Training-time waveform augmentations of preprocess.py:56-90,137-140 (time shift, Gaussian noise, resample-by-index
  * "pitch shift") for a batch, fused with the pad / trim to n_target (:151-156).  params: [batch][4] doubles drawn on
  * the host {shift mode 0 none / 1 right / 2 left, shift in samples, noise on, index step or 0}.  The noise comes from
- * a counter-based generator keyed by (seed, utterance, sample), not from torch's stream. */
-MMSA_API int mmsa_augment_wave(const float* in, long in_stride, int n_in, const double* params, float noise_factor,
-                               unsigned long long seed, float* out, int n_target, int batch, void* stream);
+ * a counter-based generator keyed by (seed, utterance, sample), not from torch's stream.  lens: null, or [batch] ints:
+ * row b holds an utterance of lens[b] <= n_in samples and is augmented as a signal of that length. */
+MMSA_API int mmsa_augment_wave(const float* in, long in_stride, int n_in, const int* lens, const double* params,
+                               float noise_factor, unsigned long long seed, float* out, int n_target, int batch,
+                               void* stream);
 /* Resampling ahead of the mel stage: torchaudio.transforms.Resample's sinc interpolation (Hann window,
  * lowpass_filter_width 6, rolloff 0.99) as applied at preprocess.py:131-134, fused with the mono mix (:127-129) and
  * the pad / trim to n_out samples (:151-156).  mmsa_resample_filters_host builds the filter bank kernT[K][ld] on the

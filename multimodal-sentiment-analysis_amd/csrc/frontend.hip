@@ -371,17 +371,27 @@ MMSA_EXPORT int mmsa_resample_fwd(const float* pcm, int channels, long T, long s
 //   [0] shift mode: 0 none, 1 right, 2 left      [1] shift in samples (0 with mode 1/2 silences the utterance, as the
 //   reference's empty `[:-0]` slices do)         [2] 1 = add Gaussian noise       [3] resampling factor (0 = none)
 // Composition: out[j] = aug[idx(j)], idx(j) = trunc(float(j * factor)) clamped to n_in-1 for j < ceil(n_in / factor),
-// aug[i] = shifted[i] + noise_factor * N(0,1).  The noise is a counter-based Box-Muller draw (seed, utterance, sample):
+// aug[i] = shifted[i] + noise_factor * N(0,1).  With `lens` (optional, one int per utterance) row b holds an utterance of
+// lens[b] <= n_in samples and is augmented as a signal of that length (an empty one gives zeros).  The noise is a counter-based Box-Muller draw (seed, utterance, sample):
 // the same distribution as the reference's torch.randn_like, not the same stream.
 namespace {
 
 __global__ __launch_bounds__(256) void augment_wave_kernel(const float* __restrict__ in, long in_stride, int n_in,
+                                                           const int* __restrict__ lens,
                                                            const double* __restrict__ params, float noise_factor,
                                                            unsigned long long seed, float* __restrict__ out,
                                                            int n_target) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n_target) return;
+  if (lens) {
+    const int n_row = lens[b];
+    n_in = n_row < n_in ? n_row : n_in;
+    if (n_in <= 0) {
+      out[(long)b * n_target + j] = 0.f;
+      return;
+    }
+  }
   const double* pr = params + 4 * b;
   const int mode = (int)pr[0];
   const long shift = (long)pr[1];
@@ -418,11 +428,12 @@ __global__ __launch_bounds__(256) void augment_wave_kernel(const float* __restri
 
 }  // namespace
 
-MMSA_EXPORT int mmsa_augment_wave(const float* in, long in_stride, int n_in, const double* params, float noise_factor,
-                                  unsigned long long seed, float* out, int n_target, int batch, void* stream) {
+MMSA_EXPORT int mmsa_augment_wave(const float* in, long in_stride, int n_in, const int* lens, const double* params,
+                                  float noise_factor, unsigned long long seed, float* out, int n_target, int batch,
+                                  void* stream) {
   MMSA_REQUIRE(in && params && out && n_in > 0 && n_target > 0 && batch > 0 && batch <= 65535 && in_stride >= n_in);
   dim3 grid(mmsa_cdiv(n_target, 256), batch);
-  hipLaunchKernelGGL(augment_wave_kernel, grid, dim3(256), 0, mmsa_stream(stream), in, in_stride, n_in, params,
-                     noise_factor, seed, out, n_target);
+  hipLaunchKernelGGL(augment_wave_kernel, grid, dim3(256), 0, mmsa_stream(stream), in, in_stride, n_in, lens,
+                     params, noise_factor, seed, out, n_target);
   return mmsa_launch_status();
 }

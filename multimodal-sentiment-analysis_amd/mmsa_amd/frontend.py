@@ -167,12 +167,14 @@ class AudioTransform:
     """Per-utterance interface of the reference (``transform(audio[C, T], sr) -> [1, 64, 130]`` CPU tensor).
 
     The spectrogram is computed by the HIP front end, so call it from the process that owns the GPU
-    (``DataLoader(num_workers=0)``), or use ``waveform_only=True`` in worker processes -- they then return the
-    prepared ``[1, 66150]`` waveform and the training process runs :class:`LogMelFrontEnd` on whole batches.
+    (``DataLoader(num_workers=0)``).  Inside a DataLoader worker process a call that would need the GPU raises
+    :class:`MmsaError` (never the all-zero map): the reference's loader runs its transform in four worker processes
+    (multimodal_train.py:435-442), which must not touch the GPU.  For them :meth:`for_workers` gives the CPU-only half
+    (decoded PCM -> mono utterance, picklable, fork-safe) and :meth:`process_batch` / :class:`BatchFrontEnd` the GPU
+    half, run on each collated batch in the training process: resampling, augmentations, noise gate, pad / trim and
+    the mel stage for the whole batch.
     Waveform augmentations follow preprocess.py:56-90 with the same ``random`` draw order.  ``noise_reduce`` (on, as
-    in the reference, `:142-148`) runs :class:`NoiseReducer` between the augmentations and the pad / trim; it needs the
-    GPU, so worker processes that must not touch it pass ``noise_reduce=False`` and leave that step to the training
-    process.
+    in the reference, `:142-148`) runs :class:`NoiseReducer` between the augmentations and the pad / trim.
     """
 
     def __init__(self, augment=False, device="cuda", waveform_only=False, strict=False, noise_reduce=True):
@@ -192,10 +194,26 @@ class AudioTransform:
         d["_rs"] = {}
         return d
 
+    def for_workers(self, max_samples=None) -> "WorkerAudioTransform":
+        """The transform to hand to the dataset when the loader uses worker processes; see
+        :class:`WorkerAudioTransform`."""
+        return WorkerAudioTransform(max_samples)
+
+    def batch_front_end(self) -> "BatchFrontEnd":
+        return BatchFrontEnd(self)
+
+    def _needs_gpu(self, sr) -> bool:
+        return (not self.waveform_only) or sr != SAMPLE_RATE or self.noise_reduce
+
     def _front_end(self):
         if self._fe is None:
             self._fe = LogMelFrontEnd(self.device)
         return self._fe
+
+    def _resampler(self, sr):
+        if sr not in self._rs:
+            self._rs[sr] = Resampler(sr, SAMPLE_RATE, self.device)
+        return self._rs[sr]
 
     def _reducer(self):
         if self._nr is None:
@@ -277,35 +295,93 @@ class AudioTransform:
         """``waves [B, n]`` (mono, 22 050 Hz, un-padded) -> ``[B, 1, 64, 130]`` on the GPU: the reference's
         augmented training transform for a whole batch in two launches (waveform augmentation + pad/trim, then the
         mel stage with the spectral masks).  ``rows`` / ``masks`` default to fresh draws, utterance by utterance."""
+        return self.process_batch(waves, None, SAMPLE_RATE, rows, masks, seed, return_wave, augment=True)
+
+    def process_batch(self, pcm: torch.Tensor, lengths=None, sr: int = SAMPLE_RATE, rows=None, masks=None, seed=None,
+                      return_wave=False, augment=None):
+        """The reference's whole per-utterance transform (preprocess.py:125-168) for a batch, on the GPU.
+
+        ``pcm [B, T]``: mono utterances at ``sr`` Hz, rows zero-padded to a common ``T``; ``lengths [B]``: samples each
+        row really holds (default: all ``T``).  Resampling to 22 050 Hz, then -- each utterance at its own length, as
+        the reference sees it -- the waveform augmentations (``augment``; ``rows`` / ``masks`` default to fresh draws
+        in the reference's order, utterance by utterance) and the noise gate, then pad / trim to 66 150 samples and
+        the mel stage.  Returns ``[B, 1, 64, 130]`` on the device (``return_wave``: the ``[B, 66150]`` waveforms)."""
+        augment = self.augment if augment is None else augment
         fe = self._front_end()
         dev = fe.device
-        waves = waves.to(device=dev, dtype=torch.float32)
-        if waves.stride(1) != 1:
-            waves = waves.contiguous()
-        B, n = waves.shape
-        if rows is None:
-            drawn = [self.draw_augmentation(n) for _ in range(B)]
-            rows, masks = [d[0] for d in drawn], [d[1] for d in drawn]
-        if seed is None:
-            # the reference consumes torch's generator for the noise (randn_like); so does the seed of ours
-            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        params = torch.tensor(rows, dtype=torch.float64).reshape(B, 4).to(dev)
-        if self.noise_reduce:
-            # the gate sees each utterance at its augmented length, before the pad / trim (preprocess.py:137-156)
-            lens = [n if r[3] <= 0 else int(math.ceil(n / r[3])) for r in rows]
-            aug = torch.empty((B, max(lens)), dtype=torch.float32, device=dev)
-            ops.augment_wave(waves, params, aug, 0.005, seed)
-            aug = self._reducer()(aug, lens=lens)
-            out = torch.zeros((B, TARGET_LENGTH), dtype=torch.float32, device=dev)
-            m = min(aug.shape[1], TARGET_LENGTH)
-            out[:, :m] = aug[:, :m]
+        if pcm.dim() != 2:
+            raise ValueError("pcm must be [B, T] (mono rows)")
+        x = pcm.to(device=dev, dtype=torch.float32)
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        B, n = x.shape
+        if lengths is None:
+            lens = [n] * B
         else:
-            out = torch.empty((B, TARGET_LENGTH), dtype=torch.float32, device=dev)
-            ops.augment_wave(waves, params, out, 0.005, seed)
+            lens = [int(v) for v in torch.as_tensor(lengths).flatten().tolist()]
+            if len(lens) != B or min(lens) < 0 or max(lens) > n:
+                raise ValueError("lengths must hold one count in 0..T per row")
+            lens = [max(v, 1) for v in lens]      # an empty utterance is one sample of silence (rows are zero-padded)
+        if sr != SAMPLE_RATE:
+            rs = self._resampler(sr)
+            x = rs(x.unsqueeze(1), n_out=None)
+            lens = [rs.resampled_length(v) for v in lens]
+            n = x.shape[1]
+        ragged = any(v != n for v in lens)
+
+        def on_device(vals):
+            return torch.tensor(vals, dtype=torch.int32).to(dev)
+
+        if ragged and sr != SAMPLE_RATE:
+            # what the filter rings out behind a shorter row's end belongs to no utterance
+            x.masked_fill_(torch.arange(n, device=dev)[None, :] >= on_device(lens)[:, None], 0.0)
+        if augment:
+            if rows is None:
+                drawn = [self.draw_augmentation(v) for v in lens]
+                rows, masks = [d[0] for d in drawn], [d[1] for d in drawn]
+            if seed is None:
+                # the reference consumes torch's generator for the noise (randn_like); so does the seed of ours
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            params = torch.tensor(rows, dtype=torch.float64).reshape(B, 4).to(dev)
+            lens_in = on_device(lens) if ragged else None
+            if self.noise_reduce:
+                # the gate sees each utterance at its augmented length, before the pad / trim (preprocess.py:137-156)
+                lens = [v if r[3] <= 0 else int(math.ceil(v / r[3])) for v, r in zip(lens, rows)]
+                aug = torch.empty((B, max(lens)), dtype=torch.float32, device=dev)
+                ops.augment_wave(x, params, aug, 0.005, seed, lens_in)
+                out = self._gate_pad_trim(aug, lens)
+            else:
+                out = torch.empty((B, TARGET_LENGTH), dtype=torch.float32, device=dev)
+                ops.augment_wave(x, params, out, 0.005, seed, lens_in)
+        elif self.noise_reduce:
+            out = self._gate_pad_trim(x, lens if ragged else None)
+        else:
+            out = x                  # the mel stage pads / trims
         if return_wave:
+            if out.shape[1] != TARGET_LENGTH:
+                full = torch.zeros((B, TARGET_LENGTH), dtype=torch.float32, device=dev)
+                m = min(out.shape[1], TARGET_LENGTH)
+                full[:, :m] = out[:, :m]
+                out = full
             return out
-        mk = None if masks is None else torch.tensor(masks, dtype=torch.int32).reshape(B, 4)
+        mk = None if (masks is None or not augment) else torch.tensor(masks, dtype=torch.int32).reshape(B, 4)
         return fe(out, specmask=mk)
+
+    def _gate_pad_trim(self, x, lens):
+        """Noise gate over rows of (optionally) different lengths, then zero pad / trim to 66 150 samples."""
+        B, n = x.shape
+        nr = self._reducer()
+        if lens is not None and n > 600000:
+            # rows of different lengths are gated in one chunk; longer batches go utterance by utterance
+            y = torch.zeros_like(x)
+            for b, v in enumerate(lens):
+                y[b:b + 1, :v] = nr(x[b:b + 1, :v])
+        else:
+            y = nr(x, lens=lens)
+        out = torch.zeros((B, TARGET_LENGTH), dtype=torch.float32, device=x.device)
+        m = min(n, TARGET_LENGTH)
+        out[:, :m] = y[:, :m]
+        return out
 
     def prepare_waveform(self, audio: torch.Tensor, sr: int = SAMPLE_RATE) -> torch.Tensor:
         """Everything before the mel stage: mono mix, resampling, augmentation, noise reduction, pad/trim."""
@@ -313,11 +389,9 @@ class AudioTransform:
             audio = audio.unsqueeze(0)
         if sr != SAMPLE_RATE:
             # preprocess.py:127-134: mono mix and resampling in one HIP launch (needs the process that owns the GPU)
-            if sr not in self._rs:
-                self._rs[sr] = Resampler(sr, SAMPLE_RATE, self.device)
             # augmentations and the noise gate see the full resampled length
             n_out = None if (self.augment or self.noise_reduce) else TARGET_LENGTH
-            audio = self._rs[sr](audio, n_out=n_out).cpu()
+            audio = self._resampler(sr)(audio, n_out=n_out).cpu()
         elif audio.shape[0] > 1:
             audio = audio.mean(dim=0, keepdim=True)
         if self.augment:
@@ -335,13 +409,26 @@ class AudioTransform:
 
     def __call__(self, audio, sr=SAMPLE_RATE):
         """``transform(audio[C, T], sr) -> [1, 64, 130]``.  Like the reference (preprocess.py:172-174) a failing
-        utterance is logged and answered with an all-zero map -- except for a missing / broken HIP library
-        (:class:`MmsaError`), which always propagates, and unless ``strict=True``."""
+        utterance is logged and answered with an all-zero map, unless ``strict=True`` -- and except where the failure
+        is not the utterance's: a missing / broken HIP library, a GPU that cannot be used from this process, or a call
+        from a DataLoader worker process that would need the GPU.  Those raise :class:`MmsaError` whatever ``strict``
+        says, because an all-zero map for every utterance would let a training run "succeed" on silence."""
+        if self._needs_gpu(sr):
+            from torch.utils.data import get_worker_info
+            if get_worker_info() is not None:
+                raise _lib.MmsaError(
+                    "AudioTransform was called inside a DataLoader worker process and needs the GPU there (the mel "
+                    "stage, the resampler and the noise gate are HIP kernels). Give the dataset "
+                    "AudioTransform(...).for_workers() instead and run AudioTransform(...).batch_front_end() on each "
+                    "collated batch in the training process (collate_fn=mmsa_amd.frontend.collate_utterances), or "
+                    "use DataLoader(num_workers=0).")
         try:
             return self._transform(audio, sr)
         except _lib.MmsaError:
             raise
         except Exception as e:
+            if _gpu_unusable(e):
+                raise _lib.MmsaError(f"the GPU cannot be used from this process: {e}") from e
             if self.strict:
                 raise
             import logging
@@ -358,10 +445,8 @@ class AudioTransform:
         if audio.dim() == 1:
             audio = audio.unsqueeze(0)
         if sr != SAMPLE_RATE:
-            if sr not in self._rs:
-                self._rs[sr] = Resampler(sr, SAMPLE_RATE, self.device)
             full = self.augment or self.noise_reduce       # both see the whole resampled utterance
-            audio = self._rs[sr](audio, n_out=None if full else TARGET_LENGTH)
+            audio = self._resampler(sr)(audio, n_out=None if full else TARGET_LENGTH)
         elif audio.shape[0] > 1:
             audio = audio.mean(dim=0, keepdim=True)
         if self.augment:
@@ -369,6 +454,137 @@ class AudioTransform:
         if self.noise_reduce and audio.shape[1] > 0:
             audio = self._reducer()(audio)
         return self._front_end()(audio)[0].cpu()
+
+
+def _gpu_unusable(e: Exception) -> bool:
+    """True for the errors torch raises when the GPU runtime cannot be brought up in this process (no device, no
+    driver, a forked child of a process that already initialised it): not a property of one utterance."""
+    if not isinstance(e, (RuntimeError, AssertionError)):
+        return False
+    msg = str(e)
+    return any(k in msg for k in ("CUDA", "HIP", "cuda runtime", "hipError", "NVIDIA driver", "forked subprocess"))
+
+
+class WorkerAudioTransform:
+    """CPU-only half of :class:`AudioTransform` for ``DataLoader`` worker processes (multimodal_train.py:435-442 runs the
+    dataset's transform in four of them, multimodal_dataset.py:172): holds no device object, is picklable and
+    fork-safe, and never touches the GPU.
+
+    ``t(audio[C, T], sr) -> {"pcm": [T'] float32, "length": int64 scalar, "sr": int64 scalar}``: the mono mix of
+    preprocess.py:127-129, nothing else.  With ``max_samples`` every utterance is zero-padded / cut to that many
+    samples (at the file's rate), so the loader's default collate can stack them; without it utterances keep their
+    length and the loader needs ``collate_fn=collate_utterances``, which pads each batch to its longest row.
+    Everything after the mono mix -- resampling, augmentations, noise gate, pad / trim, mel stage -- runs on the GPU
+    on the collated batch: :class:`BatchFrontEnd`.  Like the reference's transform (`:172-174`) it never raises: an
+    utterance it cannot read becomes three seconds of silence, whose map is all zeros."""
+
+    def __init__(self, max_samples=None):
+        if max_samples is not None and int(max_samples) < 1:
+            raise ValueError("max_samples must be positive")
+        self.max_samples = None if max_samples is None else int(max_samples)
+
+    def __call__(self, audio, sr=SAMPLE_RATE):
+        try:
+            audio = torch.as_tensor(audio)
+            if audio.dim() == 1:
+                audio = audio.unsqueeze(0)
+            if audio.dim() != 2:
+                raise ValueError("audio must be [channels, samples]")
+            pcm = audio.to(torch.float32)
+            pcm = pcm.mean(dim=0) if pcm.shape[0] > 1 else pcm[0]
+            sr = int(sr)
+            if sr <= 0:
+                raise ValueError("sample rate must be positive")
+        except Exception as e:
+            import logging
+            logging.getLogger(__name__).error(f"Error in audio transformation: {e}")
+            pcm, sr = torch.zeros(TARGET_LENGTH), SAMPLE_RATE
+        n = pcm.shape[0]
+        if self.max_samples is not None:
+            if n >= self.max_samples:
+                pcm, n = pcm[:self.max_samples], self.max_samples
+            else:
+                pcm = torch.nn.functional.pad(pcm, (0, self.max_samples - n))
+        return {"pcm": pcm.contiguous(), "length": torch.tensor(n, dtype=torch.int64),
+                "sr": torch.tensor(sr, dtype=torch.int64)}
+
+
+def _pad_utterances(items):
+    """List of per-utterance dicts (or the dataset's fallback tensors) -> one batch dict with rows padded to the
+    longest utterance."""
+    rows, lens, rates = [], [], []
+    for it in items:
+        if isinstance(it, dict):
+            n = int(it["length"])
+            rows.append(it["pcm"][:n] if it["pcm"].shape[0] != n else it["pcm"])
+            lens.append(n)
+            rates.append(int(it["sr"]))
+        else:
+            # multimodal_dataset.py:175-178 answers its own failures with a zero map: here, silence
+            rows.append(torch.zeros(TARGET_LENGTH))
+            lens.append(TARGET_LENGTH)
+            rates.append(SAMPLE_RATE)
+    T = max(max(lens), 1)
+    pcm = torch.zeros((len(rows), T), dtype=torch.float32)
+    for i, r in enumerate(rows):
+        pcm[i, :r.shape[0]] = r
+    return {"pcm": pcm, "length": torch.tensor(lens, dtype=torch.int64), "sr": torch.tensor(rates, dtype=torch.int64)}
+
+
+def collate_utterances(samples):
+    """``collate_fn`` for a loader whose dataset uses :class:`WorkerAudioTransform` without ``max_samples``: the
+    ``'audio'`` entries (utterances of different lengths) are padded to the longest of the batch, everything else goes
+    through torch's default collate."""
+    from torch.utils.data import default_collate
+    first = samples[0]
+    if isinstance(first, dict) and "pcm" in first:
+        return _pad_utterances(samples)
+    if isinstance(first, dict) and "audio" in first:
+        out = default_collate([{k: v for k, v in s.items() if k != "audio"} for s in samples])
+        out["audio"] = _pad_utterances([s["audio"] for s in samples])
+        return out
+    return default_collate(samples)
+
+
+class BatchFrontEnd:
+    """GPU half of the transform, called in the training process on what the loader collated from
+    :class:`WorkerAudioTransform` outputs: ``bfe(batch["audio"]) -> [B, 1, 64, 130]`` on the device, where the
+    reference's loop has ``batch['audio'].to(DEVICE)`` (multimodal_train.py:160,165).  Utterances are grouped by sample
+    rate (one group in practice) and each group runs :meth:`AudioTransform.process_batch`; augmentation decisions are
+    drawn here, utterance by utterance in batch order, from Python's ``random`` as the reference draws them."""
+
+    def __init__(self, transform: "AudioTransform" = None, **kw):
+        self.transform = transform if transform is not None else AudioTransform(**kw)
+
+    def __call__(self, audio, return_wave=False):
+        if torch.is_tensor(audio):
+            if audio.dim() == 4:
+                return audio.to(self.transform.device)        # already spectrograms
+            audio = {"pcm": audio, "length": torch.full((audio.shape[0],), audio.shape[1]),
+                     "sr": torch.full((audio.shape[0],), SAMPLE_RATE)}
+        pcm, length, sr = audio["pcm"], audio["length"].flatten().tolist(), audio["sr"].flatten().tolist()
+        if pcm.dim() != 2 or len(length) != pcm.shape[0] or len(sr) != pcm.shape[0]:
+            raise ValueError("expected {'pcm': [B, T], 'length': [B], 'sr': [B]}")
+        t = self.transform
+        rates = sorted(set(int(v) for v in sr))
+        if len(rates) == 1:
+            return t.process_batch(pcm, length, rates[0], return_wave=return_wave)
+        shape = (pcm.shape[0], TARGET_LENGTH) if return_wave else (pcm.shape[0], 1, N_MELS, N_FRAMES)
+        out = torch.empty(shape, dtype=torch.float32, device=t._front_end().device)
+        # draws stay in batch order: decisions first, for all utterances, then one launch sequence per rate
+        rs_len = [v if int(r) == SAMPLE_RATE else t._resampler(int(r)).resampled_length(max(v, 1))
+                  for v, r in zip(length, sr)]
+        drawn = [t.draw_augmentation(max(v, 1)) for v in rs_len] if t.augment else None
+        for rate in rates:
+            idx = [i for i, r in enumerate(sr) if int(r) == rate]
+            sel = torch.tensor(idx)
+            n = max(max(length[i] for i in idx), 1)
+            rows = masks = None
+            if drawn is not None:
+                rows, masks = [drawn[i][0] for i in idx], [drawn[i][1] for i in idx]
+            res = t.process_batch(pcm[sel, :n], [length[i] for i in idx], rate, rows, masks, return_wave=return_wave)
+            out[sel.to(out.device)] = res
+        return out
 
 
 def calculate_class_weights(csv_path):

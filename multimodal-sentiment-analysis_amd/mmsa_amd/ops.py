@@ -109,14 +109,17 @@ def logmel(wave: torch.Tensor, tables, out: torch.Tensor, n_target: int = 66150,
 
 
 def augment_wave(wave: torch.Tensor, params: torch.Tensor, out: torch.Tensor, noise_factor: float = 0.005,
-                 seed: int = 0):
-    """wave [B, n] + params [B, 4] float64 (shift mode, shift, noise on, index step) -> out [B, n_target]."""
+                 seed: int = 0, lens: torch.Tensor = None):
+    """wave [B, n] + params [B, 4] float64 (shift mode, shift, noise on, index step) -> out [B, n_target].
+    ``lens`` [B] int32 (optional): valid samples per row, each row augmented as a signal of its own length."""
+    if lens is not None and lens.numel() != wave.shape[0]:
+        raise ValueError("lens must hold one length per row")
     if wave.dim() != 2 or out.dim() != 2 or wave.shape[0] != out.shape[0] or tuple(params.shape) != (wave.shape[0], 4):
         raise ValueError("wave [B, n], params [B, 4], out [B, n_target]")
     if not wave.is_cuda or wave.dtype != F32 or wave.stride(1) != 1:
         raise _lib.MmsaError("wave must be a float32 GPU tensor with contiguous rows")
-    _lib.call("mmsa_augment_wave", wave.data_ptr(), wave.stride(0), wave.shape[1], _chk(params, torch.float64, "params"),
-              noise_factor, seed & ((1 << 64) - 1), _chk(out, name="out"), out.shape[1], wave.shape[0], _stream())
+    _lib.call("mmsa_augment_wave", wave.data_ptr(), wave.stride(0), wave.shape[1], _opt(lens, torch.int32, "lens"),
+              _chk(params, torch.float64, "params"), noise_factor, seed & ((1 << 64) - 1), _chk(out, name="out"), out.shape[1], wave.shape[0], _stream())
     return out
 
 

@@ -184,6 +184,50 @@ def test_audio_transform_applies_the_noise_gate_by_default():
     assert float((off - spec).abs().max()) > 0.1
 
 
+@pytest.mark.parametrize("augment", [False, True])
+@pytest.mark.parametrize("noise_reduce", [False, True])
+def test_batch_front_end_equals_the_per_utterance_transform(augment, noise_reduce):
+    """The split transform -- CPU half in loader workers (mono mix), GPU half on the collated, zero-padded batch
+    (resampling, augmentations, noise gate, pad / trim, mel stage; rows of different lengths, each handled at its own
+    length) -- gives, utterance for utterance, what the per-utterance call of preprocess.py:125-168 gives; with
+    augmentation the same `random` draws in the same order and the same noise seed."""
+    import random
+    from mmsa_amd.frontend import AudioTransform, collate_utterances
+    lengths = [52000, 16000, 33333, 4000]
+    utts = [torch.from_numpy(_noisy_speechlike(2, n, 20 + i)) for i, n in enumerate(lengths)]     # stereo, 16 kHz
+    tf = AudioTransform(augment=augment, device=DEV, strict=True, noise_reduce=noise_reduce)
+    batch = collate_utterances([tf.for_workers()(u, 16000) for u in utts])
+    assert batch["pcm"].shape == (4, 52000)
+    random.seed(5)
+    torch.manual_seed(9)
+    got = tf.batch_front_end()(batch)
+    assert got.shape == (4, 1, 64, 130) and got.is_cuda
+    if augment:
+        # the batch path draws every utterance's decisions first and then one noise seed for the batch
+        random.seed(5)
+        drawn = [tf.draw_augmentation(-(-441 * n // 320)) for n in lengths]
+        torch.manual_seed(9)
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        for b, u in enumerate(utts):
+            mono = u.mean(dim=0, keepdim=True)
+            # utterance b alone, with its own decisions; the noise generator is keyed by (seed, row, sample), so the
+            # utterance sits in row b of a batch whose other rows are silence
+            pcm = torch.zeros(4, u.shape[1])
+            pcm[b] = mono[0]
+            alone = tf.process_batch(pcm, [1] * b + [u.shape[1]] + [1] * (3 - b), 16000,
+                                     rows=[[0.0] * 4] * b + [drawn[b][0]] + [[0.0] * 4] * (3 - b),
+                                     masks=[[0] * 4] * b + [drawn[b][1]] + [[0] * 4] * (3 - b), seed=seed)
+            check(got[b], alone[b], 2e-5)
+    else:
+        for b, u in enumerate(utts):
+            check(got[b], tf(u, 16000), 2e-5)
+    # silence behind a short utterance, not the resampler's ringing: the padded batch row equals the lone utterance
+    wave = tf.batch_front_end()(batch, return_wave=True) if not augment else None
+    if wave is not None and not noise_reduce:
+        n3 = -(-441 * 4000 // 320)
+        assert not wave[3, n3:].any() and wave[3, :n3].any()
+
+
 # ------------------------------------------------------------------------------------------------ gather
 def test_embedding_gather_bit_exact():
     ops = _ops()
