@@ -298,7 +298,11 @@ MMSA_API int mmsa_ln_scale_bwd(const float* dy, int ldy, const float* x, const f
  * loops, harnesses that forbid hipMalloc).  The scratch is a 4 MiB device array inside the library, one copy per GPU;
  * the call allocates nothing.  B*N + B must not exceed 1 048 576 floats (MMSA_ERR_LIMIT otherwise, nothing launched).
  * The device that owns `stream` must be the current device.  All calls on one GPU share that GPU's array: calls that
- * overlap on one GPU (different streams without ordering) race.  Results are bit-identical to mmsa_ln_scale_bwd. */
+ * overlap on one GPU (different streams without ordering) race.  Results are bit-identical to mmsa_ln_scale_bwd.
+ * The first call on a device looks that device's copy of the array up (a mutex and one runtime query), which must not
+ * happen while a stream capture is in progress: capturing callers call mmsa_static_scratch_init() once per device,
+ * with that device current and outside any capture, before the first captured call (it is idempotent and cheap). */
+MMSA_API int mmsa_static_scratch_init(void);
 MMSA_API int mmsa_ln_scale_bwd_static(const float* dy, int ldy, const float* x, const float* gamma, const float* beta,
                                       const float* scale, const float* keep, const float* stats, float* dx,
                                       float* dgamma, float* dbeta, float* dscale, int B, int N, void* stream);

@@ -631,6 +631,13 @@ float* static_scratch_of_current_device() {
 }
 }  // namespace
 
+// Looks the current device's copy of the array up (once per device).  The first mmsa_ln_scale_bwd_static call on a
+// device does the same by itself, but that look-up is a runtime call that a stream capture in progress does not
+// allow: callers that capture call this first, outside the capture.
+MMSA_EXPORT int mmsa_static_scratch_init(void) {
+  return static_scratch_of_current_device() ? MMSA_OK : MMSA_ERR_LAUNCH;
+}
+
 MMSA_EXPORT int mmsa_ln_scale_bwd_static(const float* dy, int ldy, const float* x, const float* gamma,
                                          const float* beta, const float* scale, const float* keep,
                                          const float* stats, float* dx, float* dgamma, float* dbeta, float* dscale,

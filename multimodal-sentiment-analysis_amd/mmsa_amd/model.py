@@ -419,7 +419,7 @@ class _ModelFn(torch.autograd.Function):
         return none + tuple(views)
 
 
-# where the text branch's helper stream forks off the audio branch: -1 ahead of the stem (default), 0 behind the stem,
+# where the text branch's helper stream forks off the audio branch: -1 ahead of the stem, 0 behind the stem (default),
 # k = 1..3 behind residual block k (A/B aid)
 _TEXT_FORK_AT = int(os.environ.get("MMSA_TEXT_FORK_AT", "0"))
 # 1: the fork point is fixed there, but the text branch's kernels are enqueued behind the next block's first convolution
@@ -649,12 +649,13 @@ class MultimodalSentimentModel(nn.Module):
         ncls = self.classifier[-1].weight.shape[0]
         logits = torch.empty((B, ncls), dtype=torch.float32, device=self._arena.device)
         chunk = B if self.training else INFER_CHUNK
-        for i0 in range(0, B, chunk):
+        run = None
+        for i0 in range(0, B, max(chunk, 1)):
             i1 = min(B, i0 + chunk)
             a = audio[i0:i1] if audio is not None and self.modality != "text" else None
             t = input_ids[i0:i1] if input_ids is not None and self.modality != "audio" else None
             run = self._run(a, t, None, drops, need_grad=False, ws=ws, logits_out=logits[i0:i1])
-        if run.text is not None:
+        if run is not None and run.text is not None:
             text_engine.check_ids(run.text.err)      # the flag is sticky across the chunks
         probs = torch.empty_like(logits)
         loss = None

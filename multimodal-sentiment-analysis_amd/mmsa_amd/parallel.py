@@ -83,7 +83,7 @@ class _DirectSum:
         n = part.numel()
         if n % world:
             raise ValueError("direct all-reduce: the bucket length must be a multiple of the world size")
-        key = (part.device, n, world)
+        key = (part.device, part.dtype, n, world)
         buf = _DirectSum._scratch.get(key)
         if buf is None:
             buf = _DirectSum._scratch[key] = torch.empty((world, n // world), dtype=part.dtype, device=part.device)
@@ -129,8 +129,17 @@ def allreduce_buckets(flat: torch.Tensor, buckets, group=None, async_op: bool = 
             if not async_op:
                 h.wait()
         elif algo == "direct":
-            h = _DirectSum(flat[lo:hi], group)
-            if not async_op:
+            # every rank owns 1/world of the bucket; what does not divide goes through the backend's all-reduce
+            world = dist.get_world_size(group)
+            cut = hi - (hi - lo) % world
+            tail = None
+            if cut < hi:
+                tail = dist.all_reduce(flat[cut:hi], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+            h = _DirectSum(flat[lo:cut], group) if cut > lo else None
+            if async_op:
+                handles.extend(x for x in (h, tail) if x is not None)
+                continue
+            if h is not None:
                 h.wait()
         else:
             h = dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
@@ -205,7 +214,8 @@ class SparseRowExchange:
             raise ValueError("SparseRowExchange.pack: ids / table do not match the exchange's geometry")
         ok = (ids >= 0) & (ids < self.vocab)
         safe = torch.where(ok, ids, torch.zeros_like(ids))
-        keep = ok & first_occurrence_mask(safe)
+        # first occurrences among the VALID ids only: an id outside the table must not take row 0's slot
+        keep = ok & first_occurrence_mask(torch.where(ok, ids, torch.full_like(ids, -1)))
         self.ids.copy_(safe)
         torch.index_select(table, 0, safe, out=self.rows)
         self.rows.mul_(keep.unsqueeze(1).to(self.rows.dtype))

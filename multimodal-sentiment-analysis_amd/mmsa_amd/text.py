@@ -85,3 +85,8 @@ def text_backward(m, st, dfeat: torch.Tensor, grads: Grads, ws: Workspace):
                  st.B, st.L, st.E, st.F, padding_idx=m.embedding.padding_idx if m.embedding.padding_idx is not None else -1,
                  err=st.err, drow=ws.buf("text.drow", (ntok, st.E)), groups=ws.buf("text.groups", 5 * ntok, torch.int32),
                  id_table=id_table)
+    host = ws.objs.get("text.err_host")
+    if host is not None:
+        # the sticky flag goes to pinned host memory behind every backward (a 4-byte copy on this branch's stream,
+        # part of a captured step): the host can look at it without synchronising
+        host.copy_(st.err, non_blocking=True)

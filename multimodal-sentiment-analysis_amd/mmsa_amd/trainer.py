@@ -55,6 +55,10 @@ class TrainStep:
         self.grads = Grads({id(p): v for p, v in zip(self.arena.params, self.arena.views_of(self.g))})
         self.ws = Workspace(dev, persistent=True)
         self.frontend = frontend
+        self._err_host = None
+        if model.text_model is not None and dev.type == "cuda":
+            self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self.ws.objs["text.err_host"] = self._err_host
         self.keep = torch.ones(2, dtype=torch.float32, device=dev)
         self._keep_table = torch.tensor([[1., 1.], [0., 1.], [1., 0.], [0., 0.]], device=dev)
         self.use_graph = use_graph
@@ -269,12 +273,14 @@ class TrainStep:
         model._check_inputs(ins["audio"] if ins["wave"] is None else ins["wave"], ins["input_ids"])
         # a token id outside the embedding table raises IndexError in the reference.  Ids that arrive in host memory
         # are checked here; device-resident ids are checked by the kernels (they skip such tokens and raise a sticky
-        # flag), which check_ids() reads: after the first step and every CHECK_EVERY steps, so no step waits for it
+        # flag).  Every step copies that flag to pinned host memory, so the host sees it without waiting for the GPU:
+        # the IndexError comes at the start of the first step() that finds the copy of an offending step landed
+        # (normally the next one or the one after), and from check_ids() / state_dict(), which synchronise
         self._nstep += 1
         if ins["input_ids"] is not None:
             if not ins["input_ids"].is_cuda:
                 text_engine.check_ids_host(ins["input_ids"], model.text_model.embedding.num_embeddings)
-            elif self._nstep == 2 or self._nstep % self.CHECK_EVERY == 0:
+            elif (self._err_host is not None and int(self._err_host[0])) or self._nstep % self.CHECK_EVERY == 0:
                 self.check_ids()
         for k, t in ins.items():
             if t is not None:
@@ -359,6 +365,9 @@ class TrainStep:
         """Raises IndexError if any step since the last call saw a token id outside the embedding table (those
         tokens contributed zero rows and no gradient).  Synchronises."""
         if self.model.text_model is not None:
+            if self._err_host is not None:
+                torch.cuda.synchronize(self.arena.device)
+                self._err_host.zero_()
             text_engine.check_ids(self.ws.buf("text.err", 1, torch.int32))
 
     @torch.no_grad()
@@ -366,7 +375,10 @@ class TrainStep:
         return self.state[4]
 
     def state_dict(self):
-        """Optimiser state in ``torch.optim.AdamW.state_dict()`` layout (multimodal_train.py:347 saves that)."""
+        """Optimiser state in ``torch.optim.AdamW.state_dict()`` layout (multimodal_train.py:347 saves that).  Raises
+        IndexError instead if a step since the last check saw a token id outside the embedding table (the reference
+        would have raised before that update: nothing of it should reach a checkpoint)."""
+        self.check_ids()
         step = float(self.state[0].item())
         ms, vs = self.arena.views_of(self.m), self.arena.views_of(self.v)
         state = {i: {"step": torch.tensor(step), "exp_avg": ms[i].clone(), "exp_avg_sq": vs[i].clone()}

@@ -131,7 +131,7 @@ def test_gradients_for_a_spectrogram_of_another_length():
     close(out["logits"], o64["logits"])
     # With two utterances a single 2x2 max-pool near-tie that resolves differently moves a whole tensor's gradient by
     # 1e-3 and more in ANY fp32 evaluation (the fp32 CPU oracle is 1.9e-3 from float64 in the stem's weight on this
-    # input, 2e-4 .. 5e-3 over other seeds; tests/probe_wide_grads.py prints both kernels and the CPU side by side), so
+    # input, 2e-4 .. 5e-3 over other seeds; tools/probe_wide_grads.py prints both kernels and the CPU side by side), so
     # the bar is: 1e-3, or three times the distance of the reference's own fp32 arithmetic from float64.
     _, g32, _ = model_ref.forward_backward(sd, "audio", audio, None, label)
     for k, p in m.named_parameters():

@@ -369,3 +369,19 @@ def test_token_id_outside_the_table_raises_and_touches_no_neighbouring_gradient(
     with pytest.raises(IndexError):
         ts.check_ids()
     assert bool(torch.isfinite(m._arena.flat).all()) and not torch.equal(before, m._arena.flat)
+    # without anybody asking: the flag travels to pinned host memory behind every step, and the first step() that
+    # finds it there raises (here: the next one, because the GPU has finished); so does writing a checkpoint
+    for use_graph in (False, True):
+        ts = TrainStep(m, use_graph=use_graph)
+        good = b["input_ids"]
+        for _ in range(4):
+            ts.step(audio=b["audio"], input_ids=good, labels=b["label"])
+        ts.step(audio=b["audio"], input_ids=bad, labels=b["label"])
+        with pytest.raises(IndexError):
+            ts.state_dict()
+        ts.step(audio=b["audio"], input_ids=bad, labels=b["label"])
+        torch.cuda.synchronize()
+        with pytest.raises(IndexError):
+            ts.step(audio=b["audio"], input_ids=good, labels=b["label"])
+        ts.step(audio=b["audio"], input_ids=good, labels=b["label"])        # the flag was cleared by the raise
+        ts.state_dict()

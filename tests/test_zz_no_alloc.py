@@ -89,7 +89,9 @@ def test_static_scratch_entry_point_under_graph_capture():
         _lib.call("mmsa_ln_scale_bwd_static", dy.data_ptr(), dy.stride(0), x.data_ptr(), gamma.data_ptr(),
                   beta.data_ptr(), scale.data_ptr(), kp.data_ptr(), stats.data_ptr(), dx.data_ptr(), dgamma.data_ptr(),
                   dbeta.data_ptr(), dscale.data_ptr(), B, N, torch.cuda.current_stream().cuda_stream)
-    launch()                      # first call on this device happens outside the capture
+    # the per-device look-up of the array's address is a runtime query: done outside the capture, by the init call
+    _lib.call("mmsa_static_scratch_init")
+    _lib.call("mmsa_static_scratch_init")      # idempotent
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):

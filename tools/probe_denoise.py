@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Not collected by pytest: prints the error of the GPU noise gate against the float64 oracle on a few signals and
-the oracle's CPU rate (python tests/probe_denoise.py on a GPU box)."""
+the oracle's CPU rate (python tools/probe_denoise.py on a GPU box)."""
 import os
 import sys
 import time
