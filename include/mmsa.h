@@ -276,13 +276,18 @@ MMSA_API int mmsa_text_bwd(const float* dfeat, const float* feat, const int* arg
                            long padding_idx, long vocab, int* err, void* stream);
 
 /* ---- fusion head and classifiers: multimodal_model.py:202-225, :228-285, :365-404, :448-454. ---------------- */
+/* Dropout in this family (mmsa_dense_fwd/bwd, mmsa_bn1d_relu_fwd/bwd, mmsa_dropout): the mask of element i is a hash of
+ * (seed, i).  step: null, or a device float holding a step counter (the optimiser's) that the kernels mix into the
+ * seed, so that a launch sequence replayed from a HIP graph -- whose scalar arguments are frozen -- draws new masks
+ * every step; forward and backward of one step read the same counter value. */
 MMSA_API int mmsa_dense_fwd(const float* X, int ldx, const float* W, const float* bias, const float* gamma,
                             const float* beta, float* Y, int ldy, float* pre, float* stats, int B, int K, int N,
-                            int epilogue, float drop_p, unsigned long long seed, void* stream);
+                            int epilogue, float drop_p, unsigned long long seed, const float* step, void* stream);
 MMSA_API int mmsa_dense_bwd(const float* dY, int ldy, const float* X, int ldx, const float* pre, const float* stats,
                             const float* W, const float* gamma, const float* beta, float* dPre, float* dLn, float* dX,
                             int lddx, float* dW, float* db, float* dgamma, float* dbeta, int B, int K, int N,
-                            int epilogue, float drop_p, unsigned long long seed, int accumulate_dx, void* stream);
+                            int epilogue, float drop_p, unsigned long long seed, int accumulate_dx, const float* step,
+                            void* stream);
 /* the parameter gradients alone (after mmsa_dense_bwd was called with dW = null) */
 MMSA_API int mmsa_dense_bwd_w(const float* dPre, const float* dLn, const float* pre, const float* stats, const float* X,
                               int ldx, float* dW, float* db, float* dgamma, float* dbeta, int B, int K, int N,
@@ -353,11 +358,13 @@ MMSA_API int mmsa_softmax_ce(const float* logits, const long long* labels, float
 /* BatchNorm1d + ReLU (+dropout) of the audio-only classifier (:369-371,373-375) */
 MMSA_API int mmsa_bn1d_relu_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, long long* nbt, float momentum, float eps, int training, float* y,
-                                float* coeff, int B, int N, float drop_p, unsigned long long seed, void* stream);
+                                float* coeff, int B, int N, float drop_p, unsigned long long seed, const float* step,
+                                void* stream);
 MMSA_API int mmsa_bn1d_relu_bwd(const float* dy, const float* x, const float* coeff, float* dx, float* dgamma,
                                 float* dbeta, int B, int N, int training, float drop_p, unsigned long long seed,
-                                void* stream);
-MMSA_API int mmsa_dropout(const float* x, float* y, long n, float drop_p, unsigned long long seed, void* stream);
+                                const float* step, void* stream);
+MMSA_API int mmsa_dropout(const float* x, float* y, long n, float drop_p, unsigned long long seed, const float* step,
+                          void* stream);
 
 /* ---- loss regulariser, clipping, optimiser: multimodal_model.py:456-462; multimodal_train.py:194-195,481-485. */
 MMSA_API int mmsa_param_norms(const float* p, const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,

@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void dense_epilogue_kernel(const float* __rest
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ Y,
                                                              int ldy, float* __restrict__ stats, int N, int epi,
-                                                             float drop_p, unsigned long long seed) {
+                                                             float drop_p, unsigned long long seed,
+                                                             const float* __restrict__ step) {
+  if (step) seed += (unsigned long long)step[0] * 0x9E3779B97F4A7C15ull;   // replayed launches draw new masks
   __shared__ float red[16];
   const int b = blockIdx.x, t = threadIdx.x;
   const float* ps = pre + (long)b * N;
@@ -110,7 +112,8 @@ __global__ __launch_bounds__(256) void dense_bwd_x_kernel(const float* __restric
                                                           const float* __restrict__ beta, float* __restrict__ dPre,
                                                           float* __restrict__ dLn, float* __restrict__ dX, int ldx,
                                                           int K, int N, int epi, float drop_p, unsigned long long seed,
-                                                          int accumulate_dx) {
+                                                          int accumulate_dx, const float* __restrict__ step) {
+  if (step) seed += (unsigned long long)step[0] * 0x9E3779B97F4A7C15ull;   // replayed launches draw new masks
   extern __shared__ float sm[];
   float* g = sm;  // [N] gradient w.r.t. linear output
   __shared__ float red[16];
@@ -374,7 +377,8 @@ __global__ void bn1d_relu_fwd_kernel(const float* __restrict__ x, const float* _
                                      const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                      long long* __restrict__ nbt, float momentum, float eps, int training,
                                      float* __restrict__ y, float* __restrict__ coeff, int B, int N, float drop_p,
-                                     unsigned long long seed) {
+                                     unsigned long long seed, const float* __restrict__ step) {
+  if (step) seed += (unsigned long long)step[0] * 0x9E3779B97F4A7C15ull;   // replayed launches draw new masks
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n == 0 && training && nbt) *nbt += 1;
   if (n >= N) return;
@@ -411,7 +415,8 @@ __global__ void bn1d_relu_fwd_kernel(const float* __restrict__ x, const float* _
 __global__ void bn1d_relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                      const float* __restrict__ coeff, float* __restrict__ dx, float* __restrict__ dgamma,
                                      float* __restrict__ dbeta, int B, int N, int training, float drop_p,
-                                     unsigned long long seed) {
+                                     unsigned long long seed, const float* __restrict__ step) {
+  if (step) seed += (unsigned long long)step[0] * 0x9E3779B97F4A7C15ull;   // replayed launches draw new masks
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const float mean = coeff[n], istd = coeff[N + n], sc = coeff[2 * N + n], sh = coeff[3 * N + n];
@@ -439,7 +444,8 @@ __global__ void bn1d_relu_bwd_kernel(const float* __restrict__ dy, const float* 
 
 // y = drop(x) elementwise (text classifier's input dropout); backward is the same map applied to dy
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float drop_p,
-                               unsigned long long seed) {
+                               unsigned long long seed, const float* __restrict__ step) {
+  if (step) seed += (unsigned long long)step[0] * 0x9E3779B97F4A7C15ull;   // replayed launches draw new masks
   const float keep_scale = 1.0f / (1.0f - drop_p);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = hash_uniform(seed, (unsigned long long)i) >= drop_p ? x[i] * keep_scale : 0.f;
@@ -519,7 +525,8 @@ __global__ __launch_bounds__(256) void pair_attn_mix_bwd_kernel(const float* __r
 
 MMSA_EXPORT int mmsa_dense_fwd(const float* X, int ldx, const float* W, const float* bias, const float* gamma,
                                const float* beta, float* Y, int ldy, float* pre, float* stats, int B, int K, int N,
-                               int epilogue, float drop_p, unsigned long long seed, void* stream) {
+                               int epilogue, float drop_p, unsigned long long seed, const float* step,
+                               void* stream) {
   MMSA_REQUIRE(X && W && Y && B > 0 && B <= 65535 && K > 0 && N > 0 && ldx >= K && ldy >= N && K <= 12 * 1024);
   MMSA_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_LAST && drop_p >= 0.f && drop_p < 1.f);
   const bool has_ln = epilogue == EPI_LN_RELU || epilogue == EPI_RELU_LN || epilogue == EPI_LN || epilogue == EPI_LN_GELU;
@@ -536,7 +543,7 @@ MMSA_EXPORT int mmsa_dense_fwd(const float* X, int ldx, const float* W, const fl
       return MMSA_ERR_LAUNCH;
   } else {
     hipLaunchKernelGGL(dense_epilogue_kernel, dim3(B), dim3(256), 0, s, pre, gamma, beta, Y, ldy, stats, N, epilogue,
-                       drop_p, seed);
+                       drop_p, seed, step);
   }
   return mmsa_launch_status();
 }
@@ -546,7 +553,8 @@ MMSA_EXPORT int mmsa_dense_fwd(const float* X, int ldx, const float* W, const fl
 MMSA_EXPORT int mmsa_dense_bwd(const float* dY, int ldy, const float* X, int ldx, const float* pre, const float* stats,
                                const float* W, const float* gamma, const float* beta, float* dPre, float* dLn, float* dX,
                                int lddx, float* dW, float* db, float* dgamma, float* dbeta, int B, int K, int N,
-                               int epilogue, float drop_p, unsigned long long seed, int accumulate_dx, void* stream) {
+                               int epilogue, float drop_p, unsigned long long seed, int accumulate_dx,
+                               const float* step, void* stream) {
   MMSA_REQUIRE(dY && X && W && dPre && B > 0 && B <= 65535 && K > 0 && N > 0 && N <= 12 * 1024);
   MMSA_REQUIRE(epilogue >= EPI_NONE && epilogue <= EPI_LAST);
   const bool ln = epilogue == EPI_LN_RELU || epilogue == EPI_RELU_LN || epilogue == EPI_LN || epilogue == EPI_LN_GELU;
@@ -555,7 +563,7 @@ MMSA_EXPORT int mmsa_dense_bwd(const float* dY, int ldy, const float* X, int ldx
   hipStream_t s = mmsa_stream(stream);
   hipLaunchKernelGGL(dense_bwd_x_kernel, dim3(B, dX ? mmsa_cdiv(K, 64) : 1), dim3(256), (size_t)N * sizeof(float), s, dY,
                      ldy, pre, stats, W, gamma, beta, dPre, ln ? dLn : nullptr, dX, lddx, K, N, epilogue, drop_p, seed,
-                     accumulate_dx);
+                     accumulate_dx, step);
   if (dW) {
     const long total = (long)N * K + N;
     hipLaunchKernelGGL(dense_bwd_w_kernel, dim3(mmsa_cdiv(total, 256)), dim3(256), 0, s, dPre, dLn, pre, stats, X, ldx,
@@ -684,28 +692,30 @@ MMSA_EXPORT int mmsa_softmax_ce(const float* logits, const long long* labels, fl
 
 MMSA_EXPORT int mmsa_bn1d_relu_fwd(const float* x, const float* gamma, const float* beta, float* running_mean,
                                    float* running_var, long long* nbt, float momentum, float eps, int training, float* y,
-                                   float* coeff, int B, int N, float drop_p, unsigned long long seed, void* stream) {
+                                   float* coeff, int B, int N, float drop_p, unsigned long long seed,
+                                   const float* step, void* stream) {
   MMSA_REQUIRE(x && gamma && beta && running_mean && running_var && y && coeff && B > 0 && N > 0);
   MMSA_REQUIRE(drop_p >= 0.f && drop_p < 1.f);
   hipLaunchKernelGGL(bn1d_relu_fwd_kernel, dim3(mmsa_cdiv(N, 64)), dim3(64), 0, mmsa_stream(stream), x, gamma, beta,
-                     running_mean, running_var, nbt, momentum, eps, training, y, coeff, B, N, drop_p, seed);
+                     running_mean, running_var, nbt, momentum, eps, training, y, coeff, B, N, drop_p, seed, step);
   return mmsa_launch_status();
 }
 
 MMSA_EXPORT int mmsa_bn1d_relu_bwd(const float* dy, const float* x, const float* coeff, float* dx, float* dgamma,
                                    float* dbeta, int B, int N, int training, float drop_p, unsigned long long seed,
-                                   void* stream) {
+                                   const float* step, void* stream) {
   MMSA_REQUIRE(dy && x && coeff && dx && dgamma && dbeta && B > 0 && N > 0);
   hipLaunchKernelGGL(bn1d_relu_bwd_kernel, dim3(mmsa_cdiv(N, 64)), dim3(64), 0, mmsa_stream(stream), dy, x, coeff, dx,
-                     dgamma, dbeta, B, N, training, drop_p, seed);
+                     dgamma, dbeta, B, N, training, drop_p, seed, step);
   return mmsa_launch_status();
 }
 
-MMSA_EXPORT int mmsa_dropout(const float* x, float* y, long n, float drop_p, unsigned long long seed, void* stream) {
+MMSA_EXPORT int mmsa_dropout(const float* x, float* y, long n, float drop_p, unsigned long long seed, const float* step,
+                             void* stream) {
   MMSA_REQUIRE(x && y && n > 0 && drop_p > 0.f && drop_p < 1.f);
   long blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, mmsa_stream(stream), x, y, n, drop_p, seed);
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, mmsa_stream(stream), x, y, n, drop_p, seed, step);
   return mmsa_launch_status();
 }
 

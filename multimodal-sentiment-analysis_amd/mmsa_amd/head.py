@@ -20,8 +20,9 @@ from .workspace import Grads, Workspace
 class _Dense:
     """Bookkeeping for one Linear (+epilogue) so backward can mirror forward."""
 
-    def __init__(self, ws, name, lin, norm, epi, B, drop_p=0.0, seed=0):
+    def __init__(self, ws, name, lin, norm, epi, B, drop_p=0.0, seed=0, step=None):
         self.lin, self.norm, self.epi, self.drop_p, self.seed, self.name = lin, norm, epi, drop_p, seed, name
+        self.step = step if drop_p > 0 else None      # device-resident step counter mixed into the dropout seed
         self.N, self.K = lin.weight.shape
         ln = epi in (EPI_LN_RELU, EPI_RELU_LN, ops.EPI_LN, ops.EPI_LN_GELU)
         self.pre = ws.buf(name + ".pre", (B, self.N)) if epi != EPI_NONE else None
@@ -32,7 +33,7 @@ class _Dense:
         g = self.norm.weight if self.norm is not None else None
         b = self.norm.bias if self.norm is not None else None
         ops.dense_fwd(X, self.lin.weight, self.lin.bias, g, b, Y, self.pre, self.stats, self.epi, self.drop_p,
-                      self.seed)
+                      self.seed, self.step)
         return Y
 
     def bwd(self, ws, dY, dX, grads: Grads, accumulate_dx=False):
@@ -45,7 +46,7 @@ class _Dense:
         # and go to a helper stream (joined by the caller with fork(...).join() / at the end of the step)
         ops.dense_bwd(dY, self.X, self.pre, self.stats, self.lin.weight,
                       self.norm.weight if ln else None, self.norm.bias if ln else None, dPre, dLn, dX,
-                      None, None, None, None, self.epi, self.drop_p, self.seed, accumulate_dx)
+                      None, None, None, None, self.epi, self.drop_p, self.seed, accumulate_dx, self.step)
         with fork(ws, dY.device, 2):
             ops.dense_bwd_w(dPre, dLn, self.X, self.pre, self.stats, grads.of(self.lin.weight),
                             grads.of(self.lin.bias), grads.of(self.norm.weight) if ln else None,
@@ -83,7 +84,7 @@ def head_forward_both(model, a_feat, t_feat, labels, training, keep_a, keep_t, d
     the device, which is what lets a replayed launch sequence draw new masks every step."""
     if _use_layers():
         return head_forward_both_layers(model, a_feat, t_feat, labels, training, keep_a, keep_t, drop_p, seed,
-                                        need_grad, ws, logits_out)
+                                        need_grad, ws, logits_out, step_state)
     B, A = a_feat.shape
     T = t_feat.shape[1]
     fn, fu, cl = model.feature_normalizer, model.fusion_layer, model.classifier
@@ -191,7 +192,7 @@ def head_backward_both(model, st, dlogits, grads: Grads, ws: Workspace):
 
 
 def head_forward_both_layers(model, a_feat, t_feat, labels, training, keep_a, keep_t, drop_p, seed, need_grad,
-                             ws: Workspace, logits_out=None):
+                             ws: Workspace, logits_out=None, step_state=None):
     B = a_feat.shape[0]
     fn, fu, cl = model.feature_normalizer, model.fusion_layer, model.classifier
     st = SimpleNamespace(kind="both", B=B, a_feat=a_feat, t_feat=t_feat, keep_a=keep_a, keep_t=keep_t)
@@ -205,8 +206,8 @@ def head_forward_both_layers(model, a_feat, t_feat, labels, training, keep_a, ke
     Hd = fu.audio_projector[0].weight.shape[0]
     st.Hd = Hd
     st.P = ws.buf("head.P", (B, 2 * Hd))
-    st.pa = _Dense(ws, "head.pa", fu.audio_projector[0], fu.audio_projector[1], EPI_LN_RELU, B, p, seed + 1)
-    st.pt = _Dense(ws, "head.pt", fu.text_projector[0], fu.text_projector[1], EPI_LN_RELU, B, p, seed + 2)
+    st.pa = _Dense(ws, "head.pa", fu.audio_projector[0], fu.audio_projector[1], EPI_LN_RELU, B, p, seed + 1, step_state)
+    st.pt = _Dense(ws, "head.pt", fu.text_projector[0], fu.text_projector[1], EPI_LN_RELU, B, p, seed + 2, step_state)
     st.pa.fwd(st.an, st.P[:, :Hd])
     st.pt.fwd(st.tn, st.P[:, Hd:])
     st.att = _Dense(ws, "head.att", fu.attention[0], None, EPI_NONE, B)
@@ -214,8 +215,8 @@ def head_forward_both_layers(model, a_feat, t_feat, labels, training, keep_a, ke
     st.wts = ws.buf("head.wts", 2 * B)
     st.fused = ws.buf("head.fused", (B, Hd))
     ops.fusion_mix_fwd(st.P, st.att_out, st.wts, st.fused)
-    st.c0 = _Dense(ws, "head.c0", cl[0], cl[1], EPI_LN_RELU, B, p, seed + 3)
-    st.c1 = _Dense(ws, "head.c1", cl[4], cl[5], EPI_LN_RELU, B, p / 2, seed + 4)
+    st.c0 = _Dense(ws, "head.c0", cl[0], cl[1], EPI_LN_RELU, B, p, seed + 3, step_state)
+    st.c1 = _Dense(ws, "head.c1", cl[4], cl[5], EPI_LN_RELU, B, p / 2, seed + 4, step_state)
     st.c2 = _Dense(ws, "head.c2", cl[8], None, EPI_NONE, B)
     h1 = st.c0.fwd(st.fused, ws.buf("head.h1", (B, cl[0].weight.shape[0])))
     h2 = st.c1.fwd(h1, ws.buf("head.h2", (B, cl[4].weight.shape[0])))
@@ -254,11 +255,13 @@ def head_backward_both_layers(model, st, dlogits, grads: Grads, ws: Workspace):
     return d_a, d_t
 
 
-def head_forward_audio(model, feat, labels, training, drop_p, seed, need_grad, ws: Workspace, logits_out=None):
+def head_forward_audio(model, feat, labels, training, drop_p, seed, need_grad, ws: Workspace, logits_out=None,
+                       step_state=None):
     B = feat.shape[0]
     cl = model.classifier
     p = drop_p if training else 0.0
-    st = SimpleNamespace(kind="audio", B=B, feat=feat, training=training, p=p, seed=seed)
+    step = step_state if p > 0 else None
+    st = SimpleNamespace(kind="audio", B=B, feat=feat, training=training, p=p, seed=seed, step=step)
     st.l1 = _Dense(ws, "head.a1", cl[1], None, EPI_NONE, B)
     st.l2 = _Dense(ws, "head.a5", cl[5], None, EPI_NONE, B)
     st.l3 = _Dense(ws, "head.a9", cl[9], None, EPI_NONE, B)
@@ -267,13 +270,13 @@ def head_forward_audio(model, feat, labels, training, drop_p, seed, need_grad, w
     st.cf1 = ws.buf("head.cf1", 4 * st.z1.shape[1])
     bn = cl[2]
     ops.bn1d_relu_fwd(st.z1, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, training,
-                      st.y1, st.cf1, p, seed + 1)
+                      st.y1, st.cf1, p, seed + 1, step)
     st.z2 = st.l2.fwd(st.y1, ws.buf("head.z2", (B, cl[5].weight.shape[0])))
     st.y2 = ws.buf("head.y2", st.z2.shape)
     st.cf2 = ws.buf("head.cf2", 4 * st.z2.shape[1])
     bn = cl[6]
     ops.bn1d_relu_fwd(st.z2, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, training,
-                      st.y2, st.cf2, p / 2, seed + 2)
+                      st.y2, st.cf2, p / 2, seed + 2, step)
     logits = st.l3.fwd(st.y2, logits_out if logits_out is not None else ws.buf("head.logits", (B, cl[9].weight.shape[0])))
     return _finish(st, ws, logits, labels, B, need_grad)
 
@@ -285,28 +288,30 @@ def head_backward_audio(model, st, dlogits, grads: Grads, ws: Workspace):
     st.l3.bwd(ws, dlogits, dy2, grads)
     dz2 = ws.buf("head.dz2", st.z2.shape)
     ops.bn1d_relu_bwd(dy2, st.z2, st.cf2, dz2, grads.of(cl[6].weight), grads.of(cl[6].bias), st.training, st.p / 2,
-                      st.seed + 2)
+                      st.seed + 2, st.step)
     dy1 = ws.buf("head.dy1", st.y1.shape)
     st.l2.bwd(ws, dz2, dy1, grads)
     dz1 = ws.buf("head.dz1", st.z1.shape)
     ops.bn1d_relu_bwd(dy1, st.z1, st.cf1, dz1, grads.of(cl[2].weight), grads.of(cl[2].bias), st.training, st.p,
-                      st.seed + 1)
+                      st.seed + 1, st.step)
     dfeat = ws.buf("head.dfeat", st.feat.shape)
     st.l1.bwd(ws, dz1, dfeat, grads)
     return dfeat
 
 
-def head_forward_text(model, feat, labels, training, drop_p, seed, need_grad, ws: Workspace, logits_out=None):
+def head_forward_text(model, feat, labels, training, drop_p, seed, need_grad, ws: Workspace, logits_out=None,
+                      step_state=None):
     B = feat.shape[0]
     cl = model.classifier
     p = drop_p if training else 0.0
-    st = SimpleNamespace(kind="text", B=B, feat=feat, p=p, seed=seed)
+    step = step_state if p > 0 else None
+    st = SimpleNamespace(kind="text", B=B, feat=feat, p=p, seed=seed, step=step)
     x0 = feat
     if p > 0.0:
         x0 = ws.buf("head.x0", feat.shape)
-        ops.dropout(feat, x0, p, seed + 9)
-    st.l1 = _Dense(ws, "head.t1", cl[1], cl[3], EPI_RELU_LN, B, p, seed + 1)
-    st.l2 = _Dense(ws, "head.t5", cl[5], cl[7], EPI_RELU_LN, B, p, seed + 2)
+        ops.dropout(feat, x0, p, seed + 9, step)
+    st.l1 = _Dense(ws, "head.t1", cl[1], cl[3], EPI_RELU_LN, B, p, seed + 1, step)
+    st.l2 = _Dense(ws, "head.t5", cl[5], cl[7], EPI_RELU_LN, B, p, seed + 2, step)
     st.l3 = _Dense(ws, "head.t9", cl[9], None, EPI_NONE, B)
     h1 = st.l1.fwd(x0, ws.buf("head.h1", (B, cl[1].weight.shape[0])))
     h2 = st.l2.fwd(h1, ws.buf("head.h2", (B, cl[5].weight.shape[0])))
@@ -324,6 +329,6 @@ def head_backward_text(model, st, dlogits, grads: Grads, ws: Workspace):
     st.l1.bwd(ws, dh1, dx0, grads)
     if st.p > 0.0:
         dfeat = ws.buf("head.dfeat", st.feat.shape)
-        ops.dropout(dx0, dfeat, st.p, st.seed + 9)
+        ops.dropout(dx0, dfeat, st.p, st.seed + 9, st.step)
         return dfeat
     return dx0

@@ -548,10 +548,10 @@ class MultimodalSentimentModel(nn.Module):
                                                      self._drop_p(), seed, need_grad, ws, logits_out, grad_scale, step_state)
         elif self.modality == "audio":
             run.head = head_engine.head_forward_audio(self, a_feat, labels, training, self._drop_p(), seed, need_grad,
-                                                      ws, logits_out)
+                                                      ws, logits_out, step_state)
         else:
             run.head = head_engine.head_forward_text(self, t_feat, labels, training, self._drop_p(), seed, need_grad,
-                                                     ws, logits_out)
+                                                     ws, logits_out, step_state)
         run.loss = run.head.loss
         if labels is not None and self.modality == "both" and run.head.loss is not None:
             run.l2 = True

@@ -741,7 +741,7 @@ def _rows(t: torch.Tensor, name: str):
     return t.data_ptr(), t.stride(0)
 
 
-def dense_fwd(X, W, bias, gamma, beta, Y, pre, stats, epilogue=EPI_NONE, drop_p=0.0, seed=0):
+def dense_fwd(X, W, bias, gamma, beta, Y, pre, stats, epilogue=EPI_NONE, drop_p=0.0, seed=0, step=None):
     B, K = X.shape
     N = W.shape[0]
     if W.shape != (N, K) or Y.shape != (B, N):
@@ -753,11 +753,11 @@ def dense_fwd(X, W, bias, gamma, beta, Y, pre, stats, epilogue=EPI_NONE, drop_p=
     if stats is not None and stats.numel() != 2 * B:
         raise ValueError("dense_fwd: bad stats size")
     _lib.call("mmsa_dense_fwd", xp, ldx, _chk(W), _opt(bias), _opt(gamma), _opt(beta), yp, ldy, _opt(pre), _opt(stats),
-              B, K, N, epilogue, float(drop_p), int(seed), _stream())
+              B, K, N, epilogue, float(drop_p), int(seed), _opt(step), _stream())
 
 
 def dense_bwd(dY, X, pre, stats, W, gamma, beta, dPre, dLn, dX, dW, db, dgamma, dbeta, epilogue=EPI_NONE, drop_p=0.0,
-              seed=0, accumulate_dx=False):
+              seed=0, accumulate_dx=False, step=None):
     B, K = X.shape
     N = W.shape[0]
     if dY.shape != (B, N) or dPre.numel() != B * N:
@@ -771,7 +771,7 @@ def dense_bwd(dY, X, pre, stats, W, gamma, beta, dPre, dLn, dX, dW, db, dgamma, 
         raise ValueError("dense_bwd: bad dW/db")
     _lib.call("mmsa_dense_bwd", dyp, ldy, xp, ldx, _opt(pre), _opt(stats), _chk(W), _opt(gamma), _opt(beta), _chk(dPre),
               _opt(dLn), dxp, lddx, _opt(dW), _opt(db), _opt(dgamma), _opt(dbeta), B, K, N, epilogue, float(drop_p),
-              int(seed), int(accumulate_dx), _stream())
+              int(seed), int(accumulate_dx), _opt(step), _stream())
 
 
 def dense_bwd_w(dPre, dLn, X, pre, stats, dW, db, dgamma, dbeta, epilogue):
@@ -891,26 +891,27 @@ def softmax_ce(logits, labels, probs, loss, dlogits):
               _opt(dlogits), B, C, _stream())
 
 
-def bn1d_relu_fwd(x, gamma, beta, rmean, rvar, nbt, training, y, coeff, drop_p=0.0, seed=0):
+def bn1d_relu_fwd(x, gamma, beta, rmean, rvar, nbt, training, y, coeff, drop_p=0.0, seed=0, step=None):
     B, N = x.shape
     if y.shape != (B, N) or coeff.numel() != 4 * N:
         raise ValueError("bn1d_relu_fwd: bad sizes")
     _lib.call("mmsa_bn1d_relu_fwd", _chk(x), _chk(gamma), _chk(beta), _chk(rmean), _chk(rvar), _opt(nbt, torch.int64),
-              BN_MOMENTUM, BN_EPS, int(training), _chk(y), _chk(coeff), B, N, float(drop_p), int(seed), _stream())
+              BN_MOMENTUM, BN_EPS, int(training), _chk(y), _chk(coeff), B, N, float(drop_p), int(seed), _opt(step),
+              _stream())
 
 
-def bn1d_relu_bwd(dy, x, coeff, dx, dgamma, dbeta, training, drop_p=0.0, seed=0):
+def bn1d_relu_bwd(dy, x, coeff, dx, dgamma, dbeta, training, drop_p=0.0, seed=0, step=None):
     B, N = x.shape
     if dy.shape != (B, N) or dx.shape != (B, N):
         raise ValueError("bn1d_relu_bwd: bad sizes")
     _lib.call("mmsa_bn1d_relu_bwd", _chk(dy), _chk(x), _chk(coeff), _chk(dx), _chk(dgamma), _chk(dbeta), B, N,
-              int(training), float(drop_p), int(seed), _stream())
+              int(training), float(drop_p), int(seed), _opt(step), _stream())
 
 
-def dropout(x, y, drop_p, seed):
+def dropout(x, y, drop_p, seed, step=None):
     if x.numel() != y.numel():
         raise ValueError("dropout: size mismatch")
-    _lib.call("mmsa_dropout", _chk(x), _chk(y), x.numel(), float(drop_p), int(seed), _stream())
+    _lib.call("mmsa_dropout", _chk(x), _chk(y), x.numel(), float(drop_p), int(seed), _opt(step), _stream())
 
 
 # ---------------------------------------------------------------------------------------------- optimiser

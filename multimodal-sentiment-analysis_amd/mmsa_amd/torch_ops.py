@@ -101,7 +101,7 @@ _reg("bias_relu_maxtime_multi", "(Tensor[] ys, Tensor[] biases, int[] louts, Ten
 
 # ---- head (multimodal_model.py:202-285, 365-404, 448-454) ----------------------------------------------------------
 _reg("dense_fwd", "(Tensor X, Tensor W, Tensor? bias, Tensor? gamma, Tensor? beta, Tensor(a!) Y, Tensor(b!)? pre, "
-                  "Tensor(c!)? stats, int epilogue=0, float drop_p=0.0, int seed=0) -> ()", ops.dense_fwd)
+                  "Tensor(c!)? stats, int epilogue=0, float drop_p=0.0, int seed=0, Tensor? step=None) -> ()", ops.dense_fwd)
 _reg("ln_scale_fwd", "(Tensor x, Tensor gamma, Tensor beta, Tensor scale, Tensor? keep, Tensor(a!) y, Tensor(b!) stats)"
                      " -> ()", ops.ln_scale_fwd)
 _reg("ln_scale_bwd", "(Tensor dy, Tensor x, Tensor gamma, Tensor beta, Tensor scale, Tensor? keep, Tensor stats, "
@@ -111,4 +111,4 @@ _reg("fusion_mix_fwd", "(Tensor P, Tensor att, Tensor(a!) wts, Tensor(b!) fused)
 _reg("fusion_mix_bwd", "(Tensor dfused, Tensor P, Tensor wts, Tensor(a!) dP, Tensor(b!) datt) -> ()", ops.fusion_mix_bwd)
 _reg("softmax_ce", "(Tensor logits, Tensor? labels, Tensor(a!) probs, Tensor(b!)? loss, Tensor(c!)? dlogits) -> ()",
      ops.softmax_ce)
-_reg("dropout", "(Tensor x, Tensor(a!) y, float drop_p, int seed) -> ()", ops.dropout)
+_reg("dropout", "(Tensor x, Tensor(a!) y, float drop_p, int seed, Tensor? step=None) -> ()", ops.dropout)

@@ -118,12 +118,6 @@ class TrainStep:
             dense_from = self.arena.offsets[n_audio + 1] if self._use_sparse else split
             self._early_buckets = [(dense_from + lo, dense_from + hi) for lo, hi in
                                    parallel.make_buckets(self.g.numel() - dense_from, bucket)]
-        from .head import _use_layers
-        if use_graph and model.training and model._drop_p() > 0 and (model.modality != "both" or _use_layers()):
-            # the fused 'both' head mixes the device-resident step count into its dropout seed; the layer-by-layer
-            # kernels take the seed as a launch argument, which a captured sequence freezes
-            raise ValueError("graph replay would repeat the same dropout masks every step; use use_graph=False "
-                             "when dropout is active")
 
     # ------------------------------------------------------------------ one step's launch sequence
     def _forward_backward(self, audio, input_ids, labels, wave, phase: str = "all"):

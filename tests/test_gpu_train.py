@@ -300,30 +300,38 @@ def test_single_rank_process_group_path_equals_plain_step(overlap, monkeypatch):
         dist.destroy_process_group()
 
 
-def test_graph_replay_draws_new_dropout_masks():
-    """With the reference's default dropout the captured step still works: the fused head mixes the device-resident
-    step count into its seed, so consecutive replays drop different units, and forward and backward of one step agree
-    on the mask (a unit is zero in the forward activation exactly where its gradient is zero)."""
+@pytest.mark.parametrize("modality,act,dact", [("both", "head.h1", "head.c0.dln"), ("text", "head.h1", "head.t1.dln"),
+                                               ("audio", "head.y1", None)])
+def test_graph_replay_draws_new_dropout_masks(modality, act, dact):
+    """With the reference's default dropouts (multimodal_train.py:71-76; audio 0.5, text 0.3, fusion 0.5) the captured
+    step works for every modality: the kernels mix the device-resident step count into the dropout seed, so
+    consecutive replays drop different units, forward and backward of one step agree on the mask (a unit is zero in
+    the forward activation exactly where its gradient is zero), and two runs draw the same masks."""
     from mmsa_amd.trainer import TrainStep
-    m = seeded_model("both", vocab=SMALL_VOCAB, dropout0=False).to(DEV).train()
-    m.fusion_layer.draw_modality_dropout = lambda: (False, False)
-    ts = TrainStep(m, use_graph=True)
-    b = batch_tensors(0, 8, vocab=SMALL_VOCAB, device=DEV)
-    zero_sets, losses = [], []
-    for s in range(6):
-        losses.append(float(ts.step(**_step_inputs("both", b))))
-        h1 = ts.ws.buf("head.h1", (8, 128))
-        dln = ts.ws.buf("head.c0.dln", (8, 128))
-        torch.cuda.synchronize()
-        assert torch.equal(h1 == 0, dln == 0)
-        zero_sets.append((h1 == 0).cpu())
-    assert ts._graph is not None and all(np.isfinite(losses))
-    for a, c in zip(zero_sets[3:], zero_sets[4:]):           # replayed steps
-        assert not torch.equal(a, c)
-    dropped = float(zero_sets[-1].float().mean())
-    assert 0.55 < dropped < 0.95                              # relu zeros plus p = 0.5 dropout
-    with pytest.raises(ValueError):
-        TrainStep(seeded_model("audio", dropout0=False).to(DEV).train(), use_graph=True)
+    runs = []
+    for _ in range(2):
+        m = seeded_model(modality, vocab=SMALL_VOCAB, dropout0=False).to(DEV).train()
+        if modality == "both":
+            m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+        ts = TrainStep(m, use_graph=True)
+        b = batch_tensors(0, 8, vocab=SMALL_VOCAB, device=DEV)
+        width = {"both": 128, "text": 256, "audio": 128}[modality]
+        zero_sets, losses = [], []
+        for s in range(6):
+            losses.append(float(ts.step(**_step_inputs(modality, b))))
+            h1 = ts.ws.buf(act, (8, width))
+            torch.cuda.synchronize()
+            if dact is not None:
+                assert torch.equal(h1 == 0, ts.ws.buf(dact, (8, width)) == 0)
+            zero_sets.append((h1 == 0).cpu())
+        assert ts._graph is not None and all(np.isfinite(losses))
+        for a, c in zip(zero_sets[3:], zero_sets[4:]):           # replayed steps
+            assert not torch.equal(a, c)
+        dropped = float(zero_sets[-1].float().mean())
+        lo = {"both": 0.55, "text": 0.25, "audio": 0.55}[modality]      # both / audio: relu zeros plus p = 0.5 dropout
+        assert lo < dropped < 0.95, dropped
+        runs.append((losses, m._arena.flat.clone()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])
 
 
 def test_token_id_outside_the_table_raises_and_touches_no_neighbouring_gradient():

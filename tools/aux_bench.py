@@ -118,6 +118,51 @@ def main():
         ts2.step(wave=den[:, :66150], input_ids=ids32, labels=lab32)
     t = timeit(chain, reps=20, warm=5)
     out["pcm16k_to_train_step_B32"] = {"ms": round(t * 1e3, 3), "utt_per_s": round(32 / t)}
+    # BASELINE config 2 / config 1 shapes as graph-replayed training steps with the reference's default dropouts
+    # (multimodal_train.py:71-76): audio-only from decoded 16 kHz PCM (mono / resample -> noise gate -> mel -> step),
+    # text-only from token ids
+    torch.manual_seed(42)
+    m_audio = MultimodalSentimentModel("audio").to(DEV).train()
+    ts_a = TrainStep(m_audio, frontend=fe, use_graph=True)
+
+    def audio_chain():
+        rs(pcm, n_out=n_res, out=res)
+        nr(res, out=den)
+        ts_a.step(wave=den[:, :66150], labels=lab32)
+    t = timeit(audio_chain, reps=20, warm=5)
+    out["audio_train_B32_from_pcm16k"] = {"ms": round(t * 1e3, 3), "utt_per_s": round(32 / t), "graph": ts_a._graph is not None}
+    t = timeit(lambda: ts_a.step(wave=den[:, :66150], labels=lab32), reps=20, warm=5)
+    out["audio_train_B32_from_wave22k"] = {"ms": round(t * 1e3, 3), "utt_per_s": round(32 / t)}
+    m_text = MultimodalSentimentModel("text").to(DEV).train()
+    ts_t = TrainStep(m_text, use_graph=True)
+    t = timeit(lambda: ts_t.step(input_ids=ids32, labels=lab32), reps=20, warm=5)
+    out["text_train_B32"] = {"ms": round(t * 1e3, 3), "utt_per_s": round(32 / t), "graph": ts_t._graph is not None}
+    # the reference's own loop body (multimodal_train.py:175-202) unchanged on the drop-in model, beside TrainStep:
+    # zero_grad -> model(**inputs, labels) -> backward -> clip_grad_norm_ -> torch.optim.AdamW.step -> loss.item()
+    torch.manual_seed(42)
+    m_ref = MultimodalSentimentModel("both").to(DEV).train()
+    opt = torch.optim.AdamW(m_ref.parameters(), lr=1e-3, weight_decay=1e-4)
+    spec32 = fe(torch.from_numpy(b32["wave"]).to(DEV))
+    mask32 = (ids32 != 0).long()
+
+    def reference_loop_step():
+        opt.zero_grad()
+        o = m_ref(audio=spec32, input_ids=ids32, attention_mask=mask32, labels=lab32)
+        o["loss"].backward()
+        torch.nn.utils.clip_grad_norm_(m_ref.parameters(), max_norm=1.0)
+        opt.step()
+        _, preds = torch.max(o["logits"], 1)
+        preds.cpu()
+        return o["loss"].item()
+    t = timeit(reference_loop_step, reps=20, warm=5)
+    out["reference_loop_on_dropin_model_B32"] = {"ms": round(t * 1e3, 3), "utt_per_s": round(32 / t)}
+    for graph in (False, True):
+        torch.manual_seed(42)
+        m2 = MultimodalSentimentModel("both").to(DEV).train()
+        ts3 = TrainStep(m2, use_graph=graph)
+        t = timeit(lambda: ts3.step(audio=spec32, input_ids=ids32, labels=lab32), reps=30, warm=5)
+        out[f"trainstep_{'graph' if graph else 'eager'}_from_spectrograms_B32"] = {"ms": round(t * 1e3, 3),
+                                                                                   "utt_per_s": round(32 / t)}
     # inference, config 5: eval forward of 1024 utterances (front end included), predictions stay on the device
     model.eval()
     b = data.make_batch(0, 64, with_wave=True)
