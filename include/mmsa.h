@@ -267,12 +267,17 @@ MMSA_API int mmsa_bias_relu_maxtime_multi(const float* const* y_host, const floa
  * (the caller clears the table beforehand); rows == padding_idx get nothing; tokens outside [0, vocab) write nothing
  * and set *err (optional device int) to 1, where the reference's nn.Embedding raises IndexError.  A token that
  * occurs several times in the batch has its rows summed in ascending position, as the reference's CPU
- * embedding backward does: the result is the same bits on every run.  Workspaces: drow B*L*E floats, groups
- * 5*B*L ints, id_table 2*vocab ints (zero before the first call; every call leaves them zero again) */
+ * embedding backward does: the result is the same bits on every run.  groups: what mmsa_token_groups computed for
+ * these ids; drow: B*L*E floats of scratch.
+ * mmsa_token_groups sorts the token positions into groups of equal id (it depends on the ids only, so it can run
+ * beside the forward pass): groups 5*ntok ints, id_table 2*vocab ints (zero before the first call; every call leaves
+ * them zero again) */
+MMSA_API int mmsa_token_groups(const long long* ids, long ntok, long vocab, long padding_idx, int* groups,
+                               int* id_table, void* stream);
 MMSA_API int mmsa_text_bwd(const float* dfeat, const float* feat, const int* arg, const float* emb,
                            const long long* ids, int nconv, const int* ksize_host, const int* feat_off_host,
                            const float* const* wp_host, float* const* dW_host, float* const* dbias_host, float* dtable,
-                           float* drow, int* groups, int* id_table, int B, int L, int E, int F, int ldf,
+                           float* drow, const int* groups, int B, int L, int E, int F, int ldf,
                            long padding_idx, long vocab, int* err, void* stream);
 
 /* ---- fusion head and classifiers: multimodal_model.py:202-225, :228-285, :365-404, :448-454. ---------------- */

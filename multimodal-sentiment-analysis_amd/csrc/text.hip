@@ -345,24 +345,34 @@ MMSA_EXPORT int mmsa_bias_relu_maxtime_multi(const float* const* y, const float*
   return mmsa_launch_status();
 }
 
+// Groups the ntok token positions by token id for mmsa_text_bwd (depends on the ids only: it can run any time between
+// the arrival of the ids and the backward pass).  groups: 5*ntok ints [arrival | unsorted | seg_cnt | seg_off | members];
+// id_table: 2*vocab ints that must be zero at the first call and are left zero by every call.
+MMSA_EXPORT int mmsa_token_groups(const long long* ids, long ntok, long vocab, long padding_idx, int* groups,
+                                  int* id_table, void* stream) {
+  MMSA_REQUIRE(ids && groups && id_table && ntok > 0 && ntok < (1l << 30) && vocab > 0);
+  hipLaunchKernelGGL(token_groups_kernel, dim3(1), dim3(1024), 0, mmsa_stream(stream), ids, ntok, vocab, padding_idx,
+                     id_table, groups);
+  return mmsa_launch_status();
+}
+
 // Backward of the whole text branch.  dfeat/feat/arg: [B][ldf] with conv i's filters at columns feat_off[i]..+F.
 // emb: gathered rows [B][L][E].  wp[i]: forward-packed weights [k_i][F][E].  dW[i]: [F][E][k_i] (overwritten),
 // dbias[i]: [F] (overwritten).  dtable: [vocab][E]: the rows of the batch's tokens are overwritten, every other
 // row is left alone (the caller clears the table beforehand).  A token id outside [0, vocab) has no row: its
 // gradient is dropped and *err (optional) is set to 1.  The result does not depend on the order in which workgroups
-// run: the rows of a token that occurs several times are summed by position.  Workspaces: drow [B*L][E] floats,
-// groups 5*B*L ints, id_table 2*vocab ints that must be zero at the first call and are left zero by every call.
+// run: the rows of a token that occurs several times are summed by position.  groups: what mmsa_token_groups left
+// for these ids (5*B*L ints); drow: [B*L][E] floats of scratch.
 MMSA_EXPORT int mmsa_text_bwd(const float* dfeat, const float* feat, const int* arg, const float* emb,
                               const long long* ids, int nconv, const int* ksize, const int* feat_off,
                               const float* const* wp, float* const* dW, float* const* dbias, float* dtable,
-                              float* drow, int* groups, int* id_table, int B, int L, int E, int F, int ldf,
+                              float* drow, const int* groups, int B, int L, int E, int F, int ldf,
                               long padding_idx, long vocab, int* err, void* stream) {
   MMSA_REQUIRE(dfeat && feat && arg && emb && ids && ksize && feat_off && wp && dW && dbias && dtable && vocab > 0);
-  MMSA_REQUIRE(drow && groups && id_table && (long)B * L < (1l << 30));
+  MMSA_REQUIRE(drow && groups && (long)B * L < (1l << 30));
   MMSA_REQUIRE(nconv >= 1 && nconv <= 4 && B > 0 && B <= 65535 && L > 0 && E > 0 && E <= 1024 && E % 64 == 0 && F > 0);
   hipStream_t s = mmsa_stream(stream);
   const long ntok = (long)B * L;
-  hipLaunchKernelGGL(token_groups_kernel, dim3(1), dim3(1024), 0, s, ids, ntok, vocab, padding_idx, id_table, groups);
   TextConvs cv;
   cv.nconv = nconv;
   for (int i = 0; i < 4; ++i) {

@@ -705,10 +705,20 @@ def bias_relu_maxtime_multi(ys, biases, louts, feat, arg, B, L, F):
               _iarr(louts), n, _chk(feat), _chk(arg, torch.int32), B, L, F, n * F, _stream())
 
 
+def token_groups(ids, vocab, padding_idx, groups, id_table):
+    """Sorts the token positions of ``ids`` into groups of equal id for :func:`text_bwd` (``groups``: 5 * ids.numel()
+    int32; ``id_table``: 2 * vocab int32, zero before the first call and left zero by every call)."""
+    n = ids.numel()
+    if groups.numel() < 5 * n or id_table.numel() < 2 * vocab:
+        raise ValueError("token_groups: workspace too small")
+    _lib.call("mmsa_token_groups", _chk(ids, torch.int64, "input_ids"), n, vocab, padding_idx,
+              _chk(groups, torch.int32), _chk(id_table, torch.int32), _stream())
+
+
 def text_bwd(dfeat, feat, arg, emb, ids, ksizes, wps, dWs, dbs, dtable, B, L, E, F, padding_idx=0, err=None,
-             drow=None, groups=None, id_table=None):
-    """Workspaces (allocated here when not given): ``drow`` [B*L, E] floats, ``groups`` 5*B*L ints, ``id_table``
-    2*vocab ints that are zero before the first call (every call leaves them zero)."""
+             drow=None, groups=None):
+    """``groups``: what :func:`token_groups` left for these ids (computed here when not given); ``drow``: [B*L, E]
+    floats of scratch."""
     n = len(ksizes)
     ldf = n * F
     if dfeat.shape != (B, ldf) or feat.shape != (B, ldf) or arg.shape != (B, ldf) or emb.numel() != B * L * E:
@@ -722,14 +732,14 @@ def text_bwd(dfeat, feat, arg, emb, ids, ksizes, wps, dWs, dbs, dtable, B, L, E,
         drow = torch.empty(B * L * E, dtype=F32, device=dtable.device)
     if groups is None:
         groups = torch.empty(5 * B * L, dtype=torch.int32, device=dtable.device)
-    if id_table is None:
-        id_table = torch.zeros(2 * dtable.shape[0], dtype=torch.int32, device=dtable.device)
-    if drow.numel() < B * L * E or groups.numel() < 5 * B * L or id_table.numel() < 2 * dtable.shape[0]:
+        token_groups(ids, dtable.shape[0], padding_idx, groups,
+                     torch.zeros(2 * dtable.shape[0], dtype=torch.int32, device=dtable.device))
+    if drow.numel() < B * L * E or groups.numel() < 5 * B * L:
         raise ValueError("text_bwd: workspace too small")
     _lib.call("mmsa_text_bwd", _chk(dfeat), _chk(feat), _chk(arg, torch.int32), _chk(emb),
               _chk(ids, torch.int64), n, _iarr(ksizes), _iarr([i * F for i in range(n)]),
               _parr([_chk(w) for w in wps]), _parr([_chk(w) for w in dWs]), _parr([_chk(w) for w in dbs]),
-              _chk(dtable), _chk(drow), _chk(groups, torch.int32), _chk(id_table, torch.int32), B, L, E, F, ldf,
+              _chk(dtable), _chk(drow), _chk(groups, torch.int32), B, L, E, F, ldf,
               padding_idx, dtable.shape[0], _opt(err, torch.int32), _stream())
 
 

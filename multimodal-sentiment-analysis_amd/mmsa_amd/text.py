@@ -34,6 +34,7 @@ def text_forward(m, input_ids: torch.Tensor, need_grad: bool, ws: Workspace):
     # workspace creates it zeroed once; check_ids reads and clears it)
     st.err = ws.buf("text.err", 1, torch.int32, zero=not ws.persistent)
     ops.embedding_gather(ids, table, st.emb, st.err)
+    st.pad = m.embedding.padding_idx if m.embedding.padding_idx is not None else -1
     n = len(ksizes)
     st.feat = ws.buf("text.feat", (B, n * F))
     st.arg = ws.buf("text.arg", (B, n * F), torch.int32)
@@ -55,6 +56,16 @@ def text_forward(m, input_ids: torch.Tensor, need_grad: bool, ws: Workspace):
         for i, (conv, k) in enumerate(zip(m.convs, ksizes)):
             ops.conv_fwd(st.emb, st.wps[i], ys[i], None, B, 1, L, E, F, taps[:k])
             ops.bias_relu_maxtime(ys[i], conv.bias, st.feat, st.arg, B, L, L - k + 1, F, n * F, i * F)
+    if need_grad:
+        # what the backward needs to know about repeated tokens depends on the ids only: sorted here, beside the
+        # forward pass, where this branch has time to spare (id table: zero once, every launch leaves it zero again)
+        st.groups = ws.buf("text.groups", 5 * B * L, torch.int32)
+        ops.token_groups(ids, V, st.pad, st.groups, ws.buf("text.id_table", 2 * V, torch.int32, zero=not ws.persistent))
+        host = ws.objs.get("text.err_host")
+        if host is not None:
+            # the sticky flag goes to pinned host memory in every step (a 4-byte copy on this branch's stream, part of
+            # a captured step): the host can look at it without synchronising
+            host.copy_(st.err, non_blocking=True)
     return st.feat, st
 
 
@@ -77,16 +88,7 @@ def text_backward(m, st, dfeat: torch.Tensor, grads: Grads, ws: Workspace):
     dtable = grads.of(table)
     if not getattr(st, "dtable_zeroed", False):
         dtable.zero_()    # the kernels write the rows of this batch's tokens only
-    ntok = st.B * st.L
-    # zero once (a persistent workspace creates it zeroed): every launch leaves it zero again
-    id_table = ws.buf("text.id_table", 2 * table.shape[0], torch.int32, zero=not ws.persistent)
     ops.text_bwd(dfeat.contiguous(), st.feat, st.arg, st.emb, st.ids, st.ksizes, st.wps,
                  [grads.of(c.weight) for c in m.convs], [grads.of(c.bias) for c in m.convs], dtable,
-                 st.B, st.L, st.E, st.F, padding_idx=m.embedding.padding_idx if m.embedding.padding_idx is not None else -1,
-                 err=st.err, drow=ws.buf("text.drow", (ntok, st.E)), groups=ws.buf("text.groups", 5 * ntok, torch.int32),
-                 id_table=id_table)
-    host = ws.objs.get("text.err_host")
-    if host is not None:
-        # the sticky flag goes to pinned host memory behind every backward (a 4-byte copy on this branch's stream,
-        # part of a captured step): the host can look at it without synchronising
-        host.copy_(st.err, non_blocking=True)
+                 st.B, st.L, st.E, st.F, padding_idx=st.pad, err=st.err, drow=ws.buf("text.drow", (st.B * st.L, st.E)),
+                 groups=st.groups)
