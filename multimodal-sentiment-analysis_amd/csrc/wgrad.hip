@@ -12,15 +12,21 @@
 // requests for the NEXT strip: R image rows of X with a zero halo ([R+2][W+2][32 cin]; halo and rows outside the image
 // come from out-of-range buffer offsets, which read as zero) and of dY ([R][W][64 cout], and the shortcut's dY1
 // alike), 1 KiB per wave instruction, into the other of two LDS buffers.  Then it works on the current strip with
-// v_mfma_f32_32x32x2_f32: wave (jt, q, rh) owns output columns cout0 + 32 jt .. + 31, taps 0-4 (q = 0) or 5-8 (q = 1;
-// with the shortcut a fifth product X(centre) * dY1), i.e. five or four 32 x 32 accumulators that live in registers
-// across all strips, and half rh of the strip's positions.  The two waves of a SIMD have opposite q, so every SIMD
+// v_mfma_f32_32x32x2_f32: wave (jt, q, rh) owns output columns cout0 + 32 jt .. + 31, taps 0-4 (q = 0) or 5-8 (q = 1),
+// i.e. five or four 32 x 32 accumulators that live in registers across all strips, and half rh of the strip's
+// positions.  The two waves of a SIMD have opposite q, so every SIMD
 // carries nine products per step and each wave's address arithmetic and LDS reads hide under its partner's MFMAs.
 // Every operand is one conflict-free ds_read_b32 (a lane half reads 32 consecutive channels of one position); the
 // reads of step s+1 are issued among the MFMAs of step s.  One barrier per strip hands the filled buffer over and
 // the drained one back, so the DMA of strip k+1 runs under the matrix work of strip k (the first generation staged
 // through registers between two barriers and left the matrix pipe idle for a quarter of the kernel).  At the end the
 // rh halves are added through LDS.
+//
+// The 1x1 shortcut's gradient (same X, its own dY1) is a second pass over the workgroup's strips inside the same
+// launch: the strips stream through the same two buffers once more with dY1 in dY's place, and every wave forms the
+// single product X(centre) * dY1 for a quarter of each strip's positions.  (Staging dY1 beside dY in the first pass
+// halves the strip height that fits in LDS -- one image row at width 65 -- and with it the 3x3 products' efficiency:
+// 46 / 62 / 70 TFLOP/s for the three blocks' launches against 72 / 88 / 95 without the shortcut.)
 //
 // Reduction: wgrad_reduce_multi_kernel sums the slabs of any number of layers in one launch, into the reference's
 // [Cout][Cin][kh][kw] layout.
@@ -51,6 +57,7 @@ static size_t wg2_lds_budget() {
   return (size_t)kb * 1024;
 }
 constexpr size_t WG2_PARK_BYTES = 4 * 5 * 16 * 64 * 4;
+constexpr size_t WG2_PARK1_BYTES = 6 * 16 * 64 * 4;
 
 struct Wg2Plan {
   int R, strips_per_img, nstrips, nsplit;
@@ -69,12 +76,12 @@ Wg2Plan wg2_plan(int B, int H, int W, int Cin, int Cout, bool sc) {
   long best_cost = 0;
   for (int R = 1; R <= H && R <= 16; ++R) {
     const int xp = ((R + 2) * WP + 7) / 8, yp = (R * W + 3) / 4;
-    const int pieces = xp + yp * (sc ? 2 : 1);
+    const int pieces = xp + yp;
     if (2 * (size_t)pieces * 1024 > wg2_lds_budget() || (pieces + 7) / 8 > WG2_MAXP) break;
     const long cost = (long)((H + R - 1) / R) * (R + 1);
     if (!best || cost <= best_cost) { best = R; best_cost = cost; }
   }
-  if (!best) return p;   // R = 0: two one-row strips do not fit (rows wider than about 120 positions, 85 with shortcut)
+  if (!best) return p;   // R = 0: two one-row strips do not fit (rows wider than about 120 positions)
   p.R = best;
   p.strips_per_img = (H + best - 1) / best;
   p.nstrips = B * p.strips_per_img;
@@ -92,8 +99,10 @@ Wg2Plan wg2_plan(int B, int H, int W, int Cin, int Cout, bool sc) {
   if (nsplit > p.nstrips) nsplit = p.nstrips;
   const int per = (p.nstrips + nsplit - 1) / nsplit;      // strips per workgroup, evenly dealt
   p.nsplit = (p.nstrips + per - 1) / per;
-  p.shmem = 2 * (size_t)(p.xpieces + p.ypieces * (sc ? 2 : 1)) * 1024;
-  if (p.shmem < WG2_PARK_BYTES) p.shmem = WG2_PARK_BYTES;     // the epilogue parks four waves' accumulators
+  p.shmem = 2 * (size_t)(p.xpieces + p.ypieces) * 1024;
+  // the epilogue parks four waves' accumulators, and six waves' shortcut accumulators behind them
+  const size_t park = WG2_PARK_BYTES + (sc ? WG2_PARK1_BYTES : 0);
+  if (p.shmem < park) p.shmem = park;
   return p;
 }
 
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
   const int cin0 = ((int)blockIdx.x / cgroups) * 32;
   const int cout0 = ((int)blockIdx.x % cgroups) * 64;
   const int xfl = xpieces * 256, yfl = ypieces * 256;                 // floats per region
-  const int buf_fl = xfl + yfl * (SC ? 2 : 1);
+  const int buf_fl = xfl + yfl;
   const int first = blockIdx.y;
   const int count = (nstrips - first + nsplit - 1) / nsplit;          // strips first, first + nsplit, ...
 
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
   // 256 B.  Per lane and piece, fixed for the whole kernel: the byte offset relative to the strip's first row, and the
   // image row relative to it (a value that fails every row test marks a lane that always reads zero: halo columns,
   // positions past the end of the strip).
-  const int total = xpieces + ypieces * (SC ? 2 : 1);
+  const int total = xpieces + ypieces;
   int rel[WG2_MAXP], row[WG2_MAXP];
 #pragma unroll
   for (int i = 0; i < WG2_MAXP; ++i) {
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
         row[i] = r - 1;
       }
     } else if (p < total) {
-      const int py = (p - xpieces) % ypieces;
+      const int py = p - xpieces;
       const int pos = 4 * py + (lane >> 4), c4 = lane & 15;
       const int r = pos / W, c = pos - r * W;
       if (r < R) {
@@ -175,13 +184,14 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
       }
     }
   }
-  auto request = [&](int k) {   // strip number k of this workgroup -> buffer k & 1
+  // strip number k of this workgroup -> buffer slot & 1 (ry: the gradient map that fills the dY region)
+  auto request = [&](int k, int slot, const __amdgpu_buffer_rsrc_t& ry) {
     const int strip = first + k * nsplit;
     const int b = strip / strips_per_img;
     const int r0 = (strip - b * strips_per_img) * R;
     const int xbase = ((b * g.H + r0) * W) * g.Cin * 4;
     const int ybase = ((b * g.H + r0) * W) * g.Cout * 4;
-    float* buf = lds + (k & 1) * buf_fl;
+    float* buf = lds + (slot & 1) * buf_fl;
 #pragma unroll
     for (int i = 0; i < WG2_MAXP; ++i) {
       const int p = w8 + 8 * i;        // uniform
@@ -190,11 +200,8 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
       if (p < xpieces) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_void*)(buf + p * 256), 16, ok ? xbase + rel[i] : WG2_OOB, 0, 0,
                                                  0);
-      } else if (!SC || p < xpieces + ypieces) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rY, (lds_void*)(buf + p * 256), 16, ok ? ybase + rel[i] : WG2_OOB, 0, 0,
-                                                 0);
       } else {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rY1, (lds_void*)(buf + p * 256), 16, ok ? ybase + rel[i] : WG2_OOB, 0, 0,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_void*)(buf + p * 256), 16, ok ? ybase + rel[i] : WG2_OOB, 0, 0,
                                                  0);
       }
     }
@@ -203,7 +210,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
   // ------------------------------------------------------------------------------------------ matrix plan
   const int li = lane & 31, kk = lane >> 5;
   // q = 0: taps 0..4 (row above: dw -1, 0, +1; centre row: dw -1, 0); q = 1: taps 5..8 (centre row: dw +1; row below:
-  // dw -1, 0, +1) and, with the shortcut, the centre position against dY1 as a fifth product.  The taps of one image
+  // dw -1, 0, +1).  The taps of one image
   // row are 128 bytes apart in the strip, so each step needs two X addresses (a full row of three taps, the centre
   // row) and constant offsets; a lane half (kk) handles one of the step's two positions.
   const int t_first = q == 0 ? 0 : 5;
@@ -212,6 +219,9 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
   for (int i = 0; i < 5; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  f32x16 acc1, acc1b;                        // the shortcut's 32 cin x 32 cout block (second pass), even / odd steps
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc1[r] = acc1b[r] = 0.f;
 
   const int nsteps = (W + 1) >> 1;           // steps per image row (two positions each)
   const int T = R * nsteps;                  // steps per strip, row by row
@@ -223,21 +233,21 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
   const int dx_wrap = WP * 128 - (nsteps - 1) * 256, dy_wrap = W * 256 - (nsteps - 1) * 512;
   constexpr bool ODD = WFIX ? (WFIX & 1) != 0 : true;   // the last step of an odd-width row has one position only
 
-  // One strip.  QSEL 0 / 1 / 2: taps 0-4 / taps 5-8 / taps 5-8 and the shortcut.  Two operand sets alternate: the LDS
+  // One strip.  QSEL 0 / 1: taps 0-4 / taps 5-8.  Two operand sets alternate: the LDS
   // reads of step s+1 are issued among the MFMAs of step s.  Scalars walk the wave's steps row by row (xs / ys: byte
   // offsets of the step's first position).  One X address per step: the upper of the two image rows the wave's
   // taps touch, at dw = -1; the other row is one strip pitch further, its taps 128 bytes apart.
   auto strip = [&](const char* buf, auto qsel_tag) {
     constexpr int QSEL = decltype(qsel_tag)::value;
     constexpr int TC = QSEL == 1 ? 4 : 5;
+    static_assert(QSEL == 0 || QSEL == 1, "tap group");
     const int pitch = WP * 32;                                   // floats between image rows of the strip
     const char* xb = buf + lane_x - 128 - (QSEL == 0 ? WP * 128 : 0);
     const char* yb = buf + xfl * 4 + laneY;
-    const int y1off = yfl * 4;
     int st = st_begin;
     int xs = ((r_begin + 1) * WP + 1) * 128 + st_begin * 256, ys = r_begin * W * 256 + st_begin * 512;
     struct Ops {
-      float a[5], dy, e;
+      float a[5], dy;
     };
     const float *pX, *pY;
     bool dead = false;
@@ -249,7 +259,6 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
     // the step's reads in three groups (issued between the MFMAs of the step before)
     auto read_y = [&](Ops& o) {
       o.dy = pY[0];
-      if (QSEL == 2) o.e = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pY) + y1off);
       o.a[0] = QSEL == 0 ? pX[0] : pX[64];
     };
     auto read_x1 = [&](Ops& o) {
@@ -258,11 +267,8 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
     };
     auto read_x2 = [&](Ops& o) {
       if (QSEL == 0) { o.a[3] = pX[pitch]; o.a[4] = pX[pitch + 32]; }
-      else { o.a[3] = pX[pitch + 64]; if (QSEL == 2) o.a[4] = pX[32]; }
-      if (ODD) {
-        o.dy = dead ? 0.f : o.dy;
-        if (QSEL == 2) o.e = dead ? 0.f : o.e;
-      }
+      else { o.a[3] = pX[pitch + 64]; }
+      if (ODD) o.dy = dead ? 0.f : o.dy;
     };
     auto advance = [&]() {
       const bool wrap = st == nsteps - 1;                // uniform: on to the next image row
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
       st = wrap ? 0 : st + 1;
     };
     auto mfma = [&](const Ops& o, int i) {
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[i], (QSEL == 2 && i == 4) ? o.e : o.dy, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[i], o.dy, acc[i], 0, 0, 0);
     };
     // one step: the MFMAs of `cur` with the reads of `nxt` (whose addresses are ready) between them, then the scalar
     // and address arithmetic of the step after `nxt` under the last MFMAs -- in exactly this order
@@ -317,10 +323,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
       step(o1, o0, true);
     }
     step(o0, o1, false);          // reads step nmine - 1 (or, padded, step nmine - 1 again)
-    if (padded) {
-      o1.dy = 0.f;
-      o1.e = 0.f;
-    }
+    if (padded) o1.dy = 0.f;
 #pragma unroll
     for (int i = 0; i < TC; ++i) mfma(o1, i);
   };
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
   const unsigned long long lab_t0 = __builtin_amdgcn_s_memtime(), lab_r0 = __builtin_amdgcn_s_memrealtime();
   unsigned long long lab_comp = 0, lab_wait = 0, lab_t;
 #endif
-  request(0);
+  request(0, 0, rY);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();   // strip 0 has landed
 #ifdef MMSA_LAB_STAMPS
@@ -342,8 +345,10 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
 #ifdef MMSA_LAB_STAMPS
       lab_t = __builtin_amdgcn_s_memtime();
 #endif
-      // the next strip streams into the other buffer (drained one barrier ago) under this strip's matrix work
-      if (k + 1 < count) request(k + 1);
+      // the next strip streams into the other buffer (drained one barrier ago) under this strip's matrix work; behind
+      // the last strip the shortcut's pass starts over at the workgroup's first strip
+      if (k + 1 < count) request(k + 1, k + 1, rY);
+      else if (SC) request(0, count, rY1);
       const char* buf = reinterpret_cast<const char*>(lds + (k & 1) * buf_fl);
       if (nmine > 0) strip(buf, qsel_tag);
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -357,8 +362,49 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
     }
   };
   if (q == 0) strips(std::integral_constant<int, 0>{});
-  else if (SC) strips(std::integral_constant<int, 2>{});
   else strips(std::integral_constant<int, 1>{});
+
+  // Second pass (shortcut): strip k of the pass sits in buffer (count + k) & 1, its dY region holds dY1.  Wave
+  // (jt, ph) takes quarter ph = 2 q + rh of the strip's steps: one product X(centre) * dY1 per step.
+  const int ph = 2 * q + rh;
+  if (SC) {
+    const int b_begin = (T * ph) / 4, b_end = (T * (ph + 1)) / 4;
+    const int rb = b_begin / nsteps, sb = b_begin - rb * nsteps;
+    for (int k = 0; k < count; ++k) {
+      if (k + 1 < count) request(k + 1, count + k + 1, rY1);
+      const char* buf = reinterpret_cast<const char*>(lds + ((count + k) & 1) * buf_fl);
+      const char* xb = buf + lane_x;                       // centre tap: the position itself
+      const char* yb = buf + xfl * 4 + laneY;
+      int st = sb;
+      int xs = ((rb + 1) * WP + 1) * 128 + sb * 256, ys = rb * W * 256 + sb * 512;
+      // two steps per trip into two accumulators: the second product does not wait for the first, and the next
+      // trip's operand reads are on their way while both run
+      auto fetch = [&](float& a, float& d) {
+        a = *reinterpret_cast<const float*>(xb + xs);
+        d = *reinterpret_cast<const float*>(yb + ys);
+        if (ODD) d = ((W & 1) && st == nsteps - 1 && kk == 1) ? 0.f : d;
+        const bool wrap = st == nsteps - 1;
+        xs += wrap ? dx_wrap : 256;
+        ys += wrap ? dy_wrap : 512;
+        st = wrap ? 0 : st + 1;
+      };
+      int i = b_begin;
+      for (; i + 1 < b_end; i += 2) {
+        float a0, d0, a1, d1;
+        fetch(a0, d0);
+        fetch(a1, d1);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, d0, acc1, 0, 0, 0);
+        acc1b = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, d1, acc1b, 0, 0, 0);
+      }
+      if (i < b_end) {
+        float a0, d0;
+        fetch(a0, d0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, d0, acc1, 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
 #ifdef MMSA_LAB_STAMPS
   const unsigned long long lab_t2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -366,6 +412,15 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
   // The two halves of each (jt, q) pair meet in LDS (all strips are consumed: the buffers are free): the waves of
   // the second half park their accumulators, the waves of the first half add them to their own, in this fixed order.
   float* park = lds + (jt + 2 * q) * (5 * 16 * 64);
+  float* park1 = lds + 4 * (5 * 16 * 64) + jt * (3 * 16 * 64);      // the shortcut's quarters 1..3 of column half jt
+  if (SC) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc1[r] += acc1b[r];
+    if (ph != 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) park1[((ph - 1) * 16 + r) * 64 + lane] = acc1[r];
+    }
+  }
   if (rh == 1) {
 #pragma unroll
     for (int i = 0; i < 5; ++i)
@@ -384,17 +439,24 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(const float* __restric
 #pragma unroll
   for (int i = 0; i < 5; ++i) {
     const int tap = t_first + i;
-    float* dst = nullptr;
-    if (tap < 9)
-      dst = out + (long)tap * g.Cin * g.Cout;
-    else if (SC)
-      dst = partial1 + (long)blockIdx.y * g.Cin * g.Cout;
-    if (dst) {
+    if (tap < 9) {
+      float* dst = out + (long)tap * g.Cin * g.Cout;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ci = cin0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
         dst[(long)ci * g.Cout + cout0 + jt * 32 + li] = acc[i][r];
       }
+    }
+  }
+  if (SC && ph == 0) {      // quarters in fixed order: 0 + 1 + 2 + 3
+    float* dst = partial1 + (long)blockIdx.y * g.Cin * g.Cout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc1[r];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v += park1[(k * 16 + r) * 64 + lane];
+      const int ci = cin0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+      dst[(long)ci * g.Cout + cout0 + jt * 32 + li] = v;
     }
   }
 #ifdef MMSA_LAB_STAMPS
