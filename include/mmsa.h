@@ -382,11 +382,17 @@ MMSA_API int mmsa_grad_norm(const float* g, const float* p, const float* tnorm, 
                             const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,
                             const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* state, void* stream);
 /* mmsa_grad_norm that also advances the step scalars in its second launch (step count + 1, bias corrections, clip
- * coefficient): follow it with mmsa_adamw_step(..., scalars_ready = 1).  multimodal_train.py:194-195. */
+ * coefficient): follow it with mmsa_adamw_step(..., scalars_ready = 1).  multimodal_train.py:194-195.
+ * sparse_tensor >= 0: that tensor (chunks sparse_chunk0 .. + sparse_nchunks of the chunk table) is a [rows][sparse_width]
+ * table -- the token embedding, multimodal_model.py:149 -- whose data gradient is zero outside the rows sparse_ids[q] of
+ * the sparse_n positions q with sparse_first[q] > 0 (the seg_cnt array mmsa_token_groups leaves); its share of the norm
+ * is then read from those rows only (the regulariser's share lambda^2 of it needs no pass at all).  -1: dense. */
 MMSA_API int mmsa_grad_norm_finish(const float* g, const float* p, const float* tnorm, float lambda,
                                    const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,
                                    const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* state,
-                                   double beta1, double beta2, float max_norm, int do_clip, void* stream);
+                                   double beta1, double beta2, float max_norm, int do_clip, int sparse_tensor,
+                                   int sparse_chunk0, int sparse_nchunks, int sparse_width, long sparse_n,
+                                   const long long* sparse_ids, const int* sparse_first, void* stream);
 /* state (8 floats): 0 step, 1 1-beta1^t, 2 sqrt(1-beta2^t), 3 clip coefficient, 4 total grad norm, 5 sum of norms.
  * The betas are doubles: torch.optim.AdamW forms 1 - beta and the bias corrections in double before anything is rounded
  * to fp32 (1 - 0.999 -> 0.001f, where 1.f - 0.999f = 0.00099998713f). */

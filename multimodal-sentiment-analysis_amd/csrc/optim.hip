@@ -18,13 +18,27 @@ namespace {
 //                          4 total grad norm, 5 sum of parameter norms
 enum { ST_STEP = 0, ST_BC1 = 1, ST_BC2S = 2, ST_CLIP = 3, ST_GNORM = 4, ST_PNORM = 5 };
 
+// One tensor of the flat buffer may be declared row-sparse: a [rows][width] table (the token embedding) whose data
+// gradient `a` is zero outside the rows ids[q] of the positions q with first[q] > 0 (what mmsa_token_groups leaves: the
+// first occurrence of every distinct valid id).  Its sum of squares is then taken over those rows only:
+//   sum_i (a_i + c b_i)^2 = c^2 ||b||^2 + sum over touched rows of a_i (a_i + 2 c b_i),   c = alpha / ||b||,
+// where c^2 ||b||^2 = alpha^2 needs no pass over b: 8 MB of rows instead of the 62 MB of table and gradient.
+struct SparseRows {
+  int tensor;                 // index of the row-sparse tensor, -1: none
+  int first_chunk, nchunks;   // its chunks
+  int width;                  // floats per row (a multiple of 4)
+  long n;                     // positions
+  const long long* ids;       // [n] row of each position
+  const int* first;           // [n] > 0 where the position is the first one holding its row
+};
+
 // sum of squares per chunk of (a[i] + alpha * b[i] * inv_norm[tensor]) -- b optional
 __global__ __launch_bounds__(256) void chunk_sumsq_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                           const float* __restrict__ tnorm, float alpha,
                                                           const long long* __restrict__ chunk_off,
                                                           const int* __restrict__ chunk_len,
                                                           const int* __restrict__ chunk_tensor,
-                                                          double* __restrict__ chunk_ss) {
+                                                          double* __restrict__ chunk_ss, const SparseRows sp) {
   __shared__ double red[16];
   const int c = blockIdx.x;
   const float* pa = a + chunk_off[c];
@@ -35,6 +49,36 @@ __global__ __launch_bounds__(256) void chunk_sumsq_kernel(const float* __restric
     const float nm = tnorm[chunk_tensor[c]];
     coef = nm > 0.f ? alpha / nm : 0.f;
     pb = b + chunk_off[c];
+  }
+  if (sp.tensor >= 0 && chunk_tensor[c] == sp.tensor) {   // uniform
+    // the tensor's chunks share its positions evenly; one wave per position, fixed order throughout
+    const int j = c - sp.first_chunk;
+    const long per = (sp.n + sp.nchunks - 1) / sp.nchunks;
+    const long lo = j * per, hi = lo + per < sp.n ? lo + per : sp.n;
+    const long base = chunk_off[sp.first_chunk];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double s = 0.0;
+    for (long q = lo + w; q < hi; q += 4) {
+      if (sp.first[q] <= 0) continue;
+      const long row = base + sp.ids[q] * sp.width;
+      float acc = 0.f;
+      for (int i = 4 * lane; i < sp.width; i += 256) {
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(a + row + i);
+        if (b) {
+          const f32x4 pv = *reinterpret_cast<const f32x4*>(b + row + i);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc = fmaf(gv[k], fmaf(2.f * coef, pv[k], gv[k]), acc);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc = fmaf(gv[k], gv[k], acc);
+        }
+      }
+      s += (double)acc;
+    }
+    if (j == 0 && threadIdx.x == 0 && coef > 0.f) s += (double)alpha * (double)alpha;
+    s = block_sum_d(s, red);
+    if (threadIdx.x == 0) chunk_ss[c] = s;
+    return;
   }
   // 16-byte loads, four fp32 partial sums per thread (a few dozen terms each), combined in double
   const int n4 = n >> 2;
@@ -254,7 +298,7 @@ MMSA_EXPORT int mmsa_param_norms(const float* p, const long long* chunk_off, con
   hipStream_t s = mmsa_stream(stream);
   if (!chunk_sums_ready)   // otherwise chunk_ss already holds the sums (written by the previous mmsa_adamw_step)
     hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, p, (const float*)nullptr,
-                       (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss);
+                       (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss, SparseRows{-1});
   hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors, tnorm,
                      sum_out, (float*)nullptr, StepScalars{});
   return mmsa_launch_status();
@@ -280,7 +324,7 @@ MMSA_EXPORT int mmsa_grad_norm(const float* g, const float* p, const float* tnor
   MMSA_REQUIRE((p == nullptr) == (tnorm == nullptr));
   hipStream_t s = mmsa_stream(stream);
   hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, g, p, tnorm, lambda, chunk_off, chunk_len,
-                     chunk_tensor, chunk_ss);
+                     chunk_tensor, chunk_ss, SparseRows{-1});
   hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors,
                      (float*)nullptr, (float*)nullptr, state + ST_GNORM, StepScalars{});
   return mmsa_launch_status();
@@ -288,17 +332,29 @@ MMSA_EXPORT int mmsa_grad_norm(const float* g, const float* p, const float* tnor
 
 // mmsa_grad_norm that also derives, in its second launch, the step scalars mmsa_adamw_step would derive (step
 // count + 1, bias corrections, clip coefficient): follow it with mmsa_adamw_step(..., scalars_ready = 1).
+// sparse_tensor >= 0 declares that tensor a [rows][sparse_width] table whose gradient is zero outside the rows
+// sparse_ids[q] of the sparse_n positions q with sparse_first[q] > 0 (mmsa_token_groups' seg_cnt): its share of the
+// norm is then taken from those rows alone; sparse_chunk0 / sparse_nchunks: the tensor's range in the chunk table.
 MMSA_EXPORT int mmsa_grad_norm_finish(const float* g, const float* p, const float* tnorm, float lambda,
                                       const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
                                       int nchunks, const int* tensor_first_chunk, int ntensors, double* chunk_ss,
                                       float* state, double beta1, double beta2, float max_norm, int do_clip,
+                                      int sparse_tensor, int sparse_chunk0, int sparse_nchunks, int sparse_width,
+                                      long sparse_n, const long long* sparse_ids, const int* sparse_first,
                                       void* stream) {
   MMSA_REQUIRE(g && chunk_off && chunk_len && chunk_tensor && tensor_first_chunk && chunk_ss && state);
   MMSA_REQUIRE(nchunks > 0 && ntensors > 0 && ntensors <= 1024);
   MMSA_REQUIRE((p == nullptr) == (tnorm == nullptr));
+  SparseRows sp{-1};
+  if (sparse_tensor >= 0) {
+    MMSA_REQUIRE(sparse_tensor < ntensors && sparse_chunk0 >= 0 && sparse_nchunks > 0);
+    MMSA_REQUIRE(sparse_chunk0 + sparse_nchunks <= nchunks && sparse_width > 0 && sparse_width % 4 == 0);
+    MMSA_REQUIRE(sparse_n > 0 && sparse_ids && sparse_first);
+    sp = SparseRows{sparse_tensor, sparse_chunk0, sparse_nchunks, sparse_width, sparse_n, sparse_ids, sparse_first};
+  }
   hipStream_t s = mmsa_stream(stream);
   hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, g, p, tnorm, lambda, chunk_off, chunk_len,
-                     chunk_tensor, chunk_ss);
+                     chunk_tensor, chunk_ss, sp);
   hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors,
                      (float*)nullptr, (float*)nullptr, state + ST_GNORM,
                      StepScalars{state, beta1, beta2, max_norm, do_clip});

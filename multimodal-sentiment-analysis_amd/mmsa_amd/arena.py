@@ -34,6 +34,7 @@ class ChunkTable:
         first.append(len(off))
         self.nchunks = len(off)
         self.ntensors = len(sizes)
+        self.first_host = first          # tensor t owns chunks first_host[t] .. first_host[t + 1]
         self.chunk_off = torch.tensor(off, dtype=torch.int64, device=device)
         self.chunk_len = torch.tensor(ln, dtype=torch.int32, device=device)
         self.chunk_tensor = torch.tensor(tid, dtype=torch.int32, device=device)

@@ -947,14 +947,25 @@ def grad_norm(gflat, table, state, pflat=None, tnorm=None, lam=0.0):
               _chk(state), _stream())
 
 
-def grad_norm_finish(gflat, table, state, beta1, beta2, max_norm, do_clip, pflat=None, tnorm=None, lam=0.0):
+def grad_norm_finish(gflat, table, state, beta1, beta2, max_norm, do_clip, pflat=None, tnorm=None, lam=0.0,
+                     sparse=None):
     """:func:`grad_norm` that also derives the step's scalars (step count, bias corrections, clip coefficient) in its
-    second launch; :func:`adamw_step` then takes ``scalars_ready=True``."""
+    second launch; :func:`adamw_step` then takes ``scalars_ready=True``.  ``sparse = (tensor index, row width, ids,
+    first)``: that tensor is a table whose gradient is zero outside the rows ``ids[q]`` with ``first[q] > 0`` (the
+    ``seg_cnt`` part of :func:`token_groups`' result); its share of the norm is read from those rows only."""
+    sp = (-1, 0, 0, 0, 0, None, None)
+    if sparse is not None:
+        t, width, ids, first = sparse
+        n = ids.numel()
+        if first.numel() != n or not 0 <= t < table.ntensors:
+            raise ValueError("grad_norm_finish: bad row-sparse tensor description")
+        sp = (t, table.first_host[t], table.first_host[t + 1] - table.first_host[t], int(width), n,
+              _chk(ids, torch.int64, "ids"), _chk(first, torch.int32, "first"))
     _lib.call("mmsa_grad_norm_finish", _chk(gflat), _opt(pflat), _opt(tnorm), float(lam),
               _chk(table.chunk_off, torch.int64), _chk(table.chunk_len, torch.int32),
               _chk(table.chunk_tensor, torch.int32), table.nchunks,
               _chk(table.tensor_first_chunk, torch.int32), table.ntensors, _chk(table.chunk_ss, torch.float64),
-              _chk(state), float(beta1), float(beta2), float(max_norm), int(do_clip), _stream())
+              _chk(state), float(beta1), float(beta2), float(max_norm), int(do_clip), *sp, _stream())
 
 
 def adamw_step(p, g, m, v, table, state, lr, beta1, beta2, eps, wd, max_norm, do_clip, tnorm=None, lam=0.0,

@@ -218,7 +218,7 @@ class TrainStep:
         ops.stamp("step.backward_done")
         if do_clip:      # the norm kernel's second launch also advances the step count and derives the clip coefficient
             ops.grad_norm_finish(self.g, a.table, self.state, self.betas[0], self.betas[1], self.max_norm, True,
-                                 a.flat if l2 else None, tn, lam)
+                                 a.flat if l2 else None, tn, lam, sparse=self._sparse_rows())
         # AdamW also leaves the per-chunk sums of squares of the UPDATED parameters behind: the next step's
         # regulariser norms need no pass of their own over the 38 MB parameter buffer
         ops.adamw_step(a.flat, self.g, self.m, self.v, a.table, self.state, self.lr, self.betas[0], self.betas[1],
@@ -226,6 +226,18 @@ class TrainStep:
                        scalars_ready=do_clip)
         self._norms_ready = l2
         ops.stamp("step.end")
+
+    def _sparse_rows(self):
+        """The embedding table's gradient holds this batch's token rows and zeros elsewhere: while it is this rank's
+        own (no exchange has added other ranks' rows) the clip norm reads those rows only."""
+        tm = self.model.text_model
+        st = getattr(self._run, "text", None) if getattr(self, "_run", None) is not None else None
+        if tm is None or st is None or self.dist or os.environ.get("MMSA_SPARSE_NORM", "1") == "0":
+            return None
+        emb = tm.embedding.weight
+        t = next(i for i, p in enumerate(self.arena.params) if p is emb)
+        n = st.ids.numel()
+        return t, emb.shape[1], st.ids, st.groups[2 * n:3 * n]
 
     @staticmethod
     def _copy_inputs(pending):
