@@ -32,6 +32,10 @@ PER_GPU_BATCH = 32
 FP32_MATRIX_PEAK_TFLOPS = 157.3      # MI355X dense fp32 MFMA peak
 HBM_PEAK_GBS = 8000.0
 TRAIN_FLOP_PER_UTT = 2_430_343_296   # forward 811.7 MFLOP x 3 minus the stem's unused data gradient
+# What the step really executes: the text branch's backward is sparse (only the arg-max window of each (utterance,
+# filter) carries gradient: ~0.4 MFLOP/utt), where the 3 x forward count charges it 2 x 98 172 928 FLOP of dense
+# data- and weight-gradient convolutions that no kernel here runs
+EXECUTED_FLOP_PER_UTT = TRAIN_FLOP_PER_UTT - 2 * 98_172_928 + 400_000
 N_DISTINCT_BATCHES = 4
 
 
@@ -254,6 +258,8 @@ def main():
                        "launch": "hip-graph replay" if use_graph else "eager"},
             "model_tflops": round(value * TRAIN_FLOP_PER_UTT / 1e12, 2),
             "model_frac_of_fp32_matrix_peak": round(value * TRAIN_FLOP_PER_UTT / 1e12 / (world * FP32_MATRIX_PEAK_TFLOPS), 4),
+            "model_tflops_executed": round(value * EXECUTED_FLOP_PER_UTT / 1e12, 2),
+            "model_frac_executed": round(value * EXECUTED_FLOP_PER_UTT / 1e12 / (world * FP32_MATRIX_PEAK_TFLOPS), 4),
             "final_loss": round(final_loss, 5),
             "roofline": roofline,
         }

@@ -350,17 +350,22 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const float* __restric
     // One step: the 16 MFMAs of tap position J on strip `slot` and weight tile `bbuf`; behind the first MFMA of each
     // half go the LDS reads of the next half -- the second half of this step, then the first half of the next step
     // (tap position JN on strip `nslot`).
+#ifndef MMSA_LAB_SKIP_TAPS
+#define MMSA_LAB_SKIP_TAPS 0   // diagnostic builds (tools/igemm_lab.hip): 1 leaves out the matrix instructions of two of
+#endif                         // every three taps while every load, fragment read and barrier stays -- what a kernel
+                               // with a third of the multiplications could gain at best
     auto step = [&](auto Jc, auto JNc, int nslot) {
       constexpr int J = decltype(Jc)::value, JN = decltype(JNc)::value;
+      constexpr bool LIVE = !(MMSA_LAB_SKIP_TAPS && J != 0);
       const int nbuf = bbuf + 1 == NB ? 0 : bbuf + 1;
-      mfma_steps(f0, 0, 1);
+      if (LIVE) mfma_steps(f0, 0, 1);
       read_half(f1, slot, pre[J], bbuf, 1);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_steps(f0, 1, 8);
-      mfma_steps(f1, 0, 1);
+      if (LIVE) mfma_steps(f0, 1, 8);
+      if (LIVE) mfma_steps(f1, 0, 1);
       read_half(f0, nslot, pre[JN], nbuf, 0);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_steps(f1, 1, 8);
+      if (LIVE) mfma_steps(f1, 1, 8);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       bbuf = nbuf;
