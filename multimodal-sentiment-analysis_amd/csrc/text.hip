@@ -129,8 +129,11 @@ struct TextConvs {
 // members[seg_off[p] .. + seg_cnt[p]) = those positions in ascending order; seg_cnt = 0 at every other position.
 // Padding tokens and ids outside the table belong to no group.  The arrival order of the counting atomics and the
 // placement of the segments vary from run to run; the sorted segments and seg_cnt do not.
+// Everything the phases hand to each other is written and read by waves of this one workgroup, which share a
+// first-level cache: workgroup scope is enough (device-scope loads would each make the round trip to memory, 30 of
+// them in a row for a token that every utterance holds).
 __device__ __forceinline__ int coherent_load(const int* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 __global__ __launch_bounds__(1024) void token_groups_kernel(const long long* __restrict__ ids, long ntok, long vocab,
@@ -154,14 +157,14 @@ __global__ __launch_bounds__(1024) void token_groups_kernel(const long long* __r
     if (arrival[p] != 0) continue;
     int* e = table + 2 * ids[p];
     const int c = coherent_load(e);
-    __hip_atomic_store(e + 1, atomicAdd(&total, c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(e + 1, atomicAdd(&total, c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __syncthreads();
   for (long p = tid; p < ntok; p += 1024) {
     const int a = arrival[p];
     if (a < 0) continue;
     const int off = coherent_load(table + 2 * ids[p] + 1);
-    __hip_atomic_store(unsorted + off + a, (int)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(unsorted + off + a, (int)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __syncthreads();
   for (long p = tid; p < ntok; p += 1024) {      // rank of p among the positions of its id
