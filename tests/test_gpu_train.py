@@ -280,6 +280,61 @@ def test_clip_norm_from_the_batchs_embedding_rows_equals_the_dense_pass(modality
         assert abs(a - c) <= 2e-6 * c, (norms["1"], norms["0"])
 
 
+def test_training_from_a_loader_with_worker_processes():
+    """The reference's data path (multimodal_train.py:412-450: the dataset's transform runs in loader worker processes)
+    with the split transform: workers return mono PCM (CPU only), the training process runs the GPU half on each
+    collated batch and steps.  Two epochs over the same eight utterances in the same order give the same losses as
+    transforming utterance by utterance in this process and stepping on the stacked maps."""
+    from torch.utils.data import DataLoader, Dataset
+    from mmsa_amd.frontend import AudioTransform, collate_utterances
+    from mmsa_amd.trainer import TrainStep
+
+    class Utterances(Dataset):
+        def __init__(self, transform):
+            self.transform = transform
+            self.b = batch_tensors(0, 8, vocab=SMALL_VOCAB)
+
+        def __len__(self):
+            return 8
+
+        def pcm(self, i):
+            g = torch.Generator().manual_seed(50 + i)
+            n = 30000 + 4000 * i                              # 16 kHz stereo utterances of different lengths
+            t = torch.arange(n) / 16000.0
+            tone = 0.2 * torch.sin(2 * np.pi * (200.0 + 40 * i) * t)
+            return torch.stack([tone, tone]) + 0.01 * torch.randn(2, n, generator=g)
+
+        def __getitem__(self, i):
+            return {"audio": self.transform(self.pcm(i), 16000), "input_ids": self.b["input_ids"][i],
+                    "attention_mask": (self.b["input_ids"][i] != 0).long(), "label": self.b["label"][i]}
+
+    tf = AudioTransform(augment=False, device=DEV)
+    ds = Utterances(tf.for_workers())
+    loader = DataLoader(ds, batch_size=4, shuffle=False, num_workers=2, collate_fn=collate_utterances, drop_last=True)
+    front = tf.batch_front_end()
+    m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+    m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+    ts = TrainStep(m)
+    got = []
+    for _ in range(2):
+        for batch in loader:
+            audio = front(batch["audio"])                      # was: batch['audio'].to(DEVICE)
+            assert audio.shape == (4, 1, 64, 130) and audio.is_cuda
+            got.append(float(ts.step(audio=audio, input_ids=batch["input_ids"].to(DEV), labels=batch["label"].to(DEV))))
+    # the same utterances through the per-utterance call of the reference's interface, in this process
+    m2 = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+    m2.fusion_layer.draw_modality_dropout = lambda: (False, False)
+    ts2 = TrainStep(m2)
+    strict = AudioTransform(augment=False, device=DEV, strict=True)
+    maps = torch.stack([strict(ds.pcm(i), 16000) for i in range(8)]).to(DEV)
+    want = []
+    for _ in range(2):
+        for lo in (0, 4):
+            want.append(float(ts2.step(audio=maps[lo:lo + 4], input_ids=ds.b["input_ids"][lo:lo + 4].to(DEV),
+                                       labels=ds.b["label"][lo:lo + 4].to(DEV))))
+    assert len(got) == 4 and np.allclose(got, want, rtol=0, atol=2e-5), (got, want)
+
+
 def test_train_from_waveforms_uses_frontend():
     from mmsa_amd.frontend import LogMelFrontEnd
     from mmsa_amd.trainer import TrainStep
