@@ -356,7 +356,7 @@ __global__ __launch_bounds__(512) void conv_igemm3_kernel(const float* __restric
                                // with a third of the multiplications could gain at best
     auto step = [&](auto Jc, auto JNc, int nslot) {
       constexpr int J = decltype(Jc)::value, JN = decltype(JNc)::value;
-      constexpr bool LIVE = !(MMSA_LAB_SKIP_TAPS && J != 0);
+      constexpr bool LIVE = MMSA_LAB_SKIP_TAPS == 0 || (MMSA_LAB_SKIP_TAPS == 1 && J == 0);   // 2: no tap at all
       const int nbuf = bbuf + 1 == NB ? 0 : bbuf + 1;
       if (LIVE) mfma_steps(f0, 0, 1);
       read_half(f1, slot, pre[J], bbuf, 1);
