@@ -228,6 +228,38 @@ def test_batch_front_end_equals_the_per_utterance_transform(augment, noise_reduc
         assert not wave[3, n3:].any() and wave[3, :n3].any()
 
 
+def test_batch_front_end_with_utterances_at_different_sample_rates():
+    """A collated batch may hold files of several rates (multimodal_dataset.py:146 takes whatever rate the file has):
+    the GPU half runs one launch sequence per rate and puts the maps back in batch order; with augmentation the
+    decisions are still drawn utterance by utterance in batch order."""
+    import random
+    from mmsa_amd.frontend import AudioTransform, collate_utterances
+    rates = [16000, 22050, 8000, 16000, 22050]
+    utts = [torch.from_numpy(_noisy_speechlike(1, 20000 + 3000 * i, 40 + i)) for i in range(5)]
+    tf = AudioTransform(augment=False, device=DEV, strict=True)
+    batch = collate_utterances([tf.for_workers()(u, r) for u, r in zip(utts, rates)])
+    assert batch["sr"].tolist() == rates
+    got = tf.batch_front_end()(batch)
+    assert got.shape == (5, 1, 64, 130)
+    for b, (u, r) in enumerate(zip(utts, rates)):
+        check(got[b], tf(u, r), 2e-5)
+    ta = AudioTransform(augment=True, device=DEV, strict=True, noise_reduce=False)
+    random.seed(3)
+    torch.manual_seed(4)
+    aug = ta.batch_front_end()(batch)
+    random.seed(3)
+    res_len = [ta._resampler(r).resampled_length(u.shape[1]) if r != 22050 else u.shape[1] for u, r in zip(utts, rates)]
+    drawn = [ta.draw_augmentation(n) for n in res_len]          # batch order, whatever the rate
+    # utterances that drew no waveform change and no mask must equal the plain transform's map
+    plain = [b for b, (row, mask) in enumerate(drawn) if row == [0.0, 0.0, 0.0, 0.0] and mask == [0, 0, 0, 0]]
+    changed = [b for b in range(5) if b not in plain]
+    assert changed, "the seed should augment at least one utterance"
+    for b in plain:
+        check(aug[b], got[b], 2e-5)
+    for b in changed:
+        assert float((aug[b] - got[b]).abs().max()) > 1e-3 or drawn[b][0][0] != 0.0
+
+
 # ------------------------------------------------------------------------------------------------ gather
 def test_embedding_gather_bit_exact():
     ops = _ops()
