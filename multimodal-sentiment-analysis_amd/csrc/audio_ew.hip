@@ -413,9 +413,9 @@ __device__ __forceinline__ void bn_finalize_body(const float* __restrict__ parti
         for (int i = sub; i < tiles_per_img; i += 8) t += stash[b * tiles_per_img + i];
       else
         for (int i = sub; i < tiles_per_img; i += 8) t += ps[(long)b * tiles_per_img + i];
-      t += __shfl_xor(t, 1, 64);
-      t += __shfl_xor(t, 2, 64);
-      t += __shfl_xor(t, 4, 64);
+      t += dpp_mov<DPP_XOR1>(t);          // (the eight lanes of an utterance are enabled together)
+      t += dpp_mov<DPP_XOR2>(t);
+      t += dpp_mov<DPP_HALF_MIRROR>(t);
       if (sub == 0) bsum[(long)b * C + c] = t;
     }
   }

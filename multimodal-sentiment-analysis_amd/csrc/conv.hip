@@ -452,8 +452,11 @@ __global__ __launch_bounds__(512) void conv_igemm_kernel(const float* __restrict
     float* red = lds;  // safe: every wave passed the loop's final barrier
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      csum[j] += __shfl_xor(csum[j], 32, 64);
-      csq[j] += __shfl_xor(csq[j], 32, 64);
+      float lo, hi;   // the two lane halves' values, the same pair in every lane
+      swap32_pair(csum[j], lo, hi);
+      csum[j] = lo + hi;
+      swap32_pair(csq[j], lo, hi);
+      csq[j] = lo + hi;
       if (lh == 0 && !loader) {
         red[(wm * 2 + 0) * BN + wn * WTN + j * 32 + li] = csum[j];
         red[(wm * 2 + 1) * BN + wn * WTN + j * 32 + li] = csq[j];

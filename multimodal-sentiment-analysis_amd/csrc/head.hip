@@ -20,30 +20,6 @@ constexpr int LPR = 16;      // lanes per output row in the forward mat-vec
 constexpr float LN_EPS = 1e-5f;
 static_assert(LPR == 16, "the mat-vec adds a row's partial sums over one 16-lane row of the cross-lane data path");
 
-// Sums over lanes on the vector ALU's own cross-lane path (DPP row operations, then the two half-swaps of gfx950) in
-// place of six trips through the LDS crossbar (ds_bpermute, some 130 cycles each, one after the other): the head is a
-// chain of short dependent stages, most of which end in one or two such sums, and the trips were over half of a
-// LayerNorm stage.  A butterfly: every lane ends with the same bits.
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141>(v);   // row_half_mirror
-  v += dpp_mov<0x140>(v);   // row_mirror
-  return v;
-}
-__device__ __forceinline__ float wsum(float v) {
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  v = row16_sum(v);
-  u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
 // slots of the pointer table (device pointers; see include/mmsa.h)
 enum Slot {
   S_AFEAT, S_TFEAT, S_AN_G, S_AN_B, S_A_SCALE, S_TN_G, S_TN_B, S_T_SCALE, S_KEEP_A, S_KEEP_T,
@@ -310,7 +286,7 @@ __device__ __forceinline__ void matvec_t(const float* __restrict__ W, const floa
 __device__ __forceinline__ float wave_row_sum(const float* v, int N) {
   float s = 0.f;
   for (int n = threadIdx.x & 63; n < N; n += 64) s += v[n];
-  return wsum(s);
+  return wave_sum(s);
 }
 
 // mean and 1/sqrt(var + eps) of v[0..N) (LDS), two passes as torch's LayerNorm, wave-redundant
@@ -321,7 +297,7 @@ __device__ __forceinline__ void row_stats(const float* v, int N, float& mean, fl
     const float d = v[n] - mean;
     q = fmaf(d, d, q);
   }
-  rstd = 1.0f / sqrtf(wsum(q) / (float)N + LN_EPS);
+  rstd = 1.0f / sqrtf(wave_sum(q) / (float)N + LN_EPS);
 }
 
 // The head's stages are short and the workgroup's sixteen waves share four vector ALUs, so a stage's time is its
@@ -390,18 +366,6 @@ __device__ __forceinline__ void ln_relu_drop_bwd(const float* d_in, float* g, fl
   __syncthreads();
 }
 
-__device__ __forceinline__ float wmax(float v) {
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  v = fmaxf(v, dpp_mov<0xB1>(v));
-  v = fmaxf(v, dpp_mov<0x4E>(v));
-  v = fmaxf(v, dpp_mov<0x141>(v));
-  v = fmaxf(v, dpp_mov<0x140>(v));
-  u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-
 // logits of utterance b (LDS) -> HBM; with labels also the gradient of the mean cross-entropy w.r.t. them,
 // (softmax - onehot) / B (multimodal_model.py:452-456 and its autograd), so the backward launch can follow without a
 // loss kernel between.  One wave, a class per lane.
@@ -415,10 +379,10 @@ __device__ __forceinline__ void write_logits(const HeadPtrs& h, const HeadDims& 
     // every lane of the wave is enabled here (the tests above are uniform); lanes beyond C carry -inf and 0
     float m = -INFINITY;
     for (int c = t; c < d.C; c += 64) m = fmaxf(m, s_pre[c]);
-    m = wmax(m);
+    m = wave_max(m);
     float sum = 0.f;
     for (int c = t; c < d.C; c += 64) sum += expf(s_pre[c] - m);
-    const float inv = 1.0f / wsum(sum);
+    const float inv = 1.0f / wave_sum(sum);
     const long long y = labels[b];
     for (int c = t; c < d.C; c += 64) {
       const float p = expf(s_pre[c] - m) * inv;

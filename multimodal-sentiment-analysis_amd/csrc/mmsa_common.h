@@ -39,20 +39,82 @@ __device__ __forceinline__ float hash_uniform(unsigned long long seed, unsigned 
 }
 
 // ---- wave / block reductions -------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Butterflies on the vector ALU's own cross-lane path (DPP row operations, then the two half-swaps of gfx950), not
+// through the LDS crossbar: a ds_bpermute round trip is some 130 cycles and a 64-lane sum chains six of them (twelve
+// for a double), which was half the run time of the one-workgroup-per-channel finishing kernels and of every
+// LayerNorm stage of the fusion head.  Every lane ends with the same bits.  Call with all 64 lanes enabled.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, 0xf, 0xf, true);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+constexpr int DPP_XOR1 = 0xB1;      // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;      // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141;   // lane i <-> 7 - i of each 8: the other quad, once the quads are uniform
+constexpr int DPP_MIRROR = 0x140;        // lane i <-> 15 - i of each 16: the other half row
+// sum over each 16-lane row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_mov<DPP_XOR1>(v);
+  v += dpp_mov<DPP_XOR2>(v);
+  v += dpp_mov<DPP_HALF_MIRROR>(v);
+  v += dpp_mov<DPP_MIRROR>(v);
   return v;
 }
+// The half-swaps exchange the odd rows (upper half) of one register with the even rows (lower half) of another; of
+// two copies of v they leave one holding the even-side and one the odd-side value in every lane.
+__device__ __forceinline__ void swap16_pair(float v, float& a, float& b) {
+  const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap32_pair(float v, float& a, float& b) {
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  float a, b;
+  v = row16_sum(v);
+  swap16_pair(v, a, b);
+  v = a + b;
+  swap32_pair(v, a, b);
+  return a + b;
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
+  v += dpp_mov<DPP_XOR1>(v);
+  v += dpp_mov<DPP_XOR2>(v);
+  v += dpp_mov<DPP_HALF_MIRROR>(v);
+  v += dpp_mov<DPP_MIRROR>(v);
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int step = 0; step < 2; ++step) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)bits, hi = (unsigned)(bits >> 32);
+    const u32x2 rl = step ? __builtin_amdgcn_permlane32_swap(lo, lo, false, false)
+                          : __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const u32x2 rh = step ? __builtin_amdgcn_permlane32_swap(hi, hi, false, false)
+                          : __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __longlong_as_double((long long)(((unsigned long long)rh[0] << 32) | rl[0])) +
+        __longlong_as_double((long long)(((unsigned long long)rh[1] << 32) | rl[1]));
+  }
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  float a, b;
+  v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
+  v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+  v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_mov<DPP_MIRROR>(v));
+  swap16_pair(v, a, b);
+  v = fmaxf(a, b);
+  swap32_pair(v, a, b);
+  return fmaxf(a, b);
 }
 
 // Sum over a whole block (blockDim.x multiple of 64, <= 1024). `red` is >= 16 floats of LDS.
