@@ -126,36 +126,89 @@ struct StepScalars {   // state == nullptr: tensor_norms_kernel leaves the step 
   int do_clip;
 };
 
-// per-tensor norms from chunk sums; out_sum = sum_t norm_t (fp32, registration order), out_l2 = sqrt(sum_t norm_t^2)
+// per-tensor norms from chunk sums; out_sum = sum_t norm_t (fp32, registration order), out_l2 = sqrt(sum_t norm_t^2).
+// One workgroup, on the step's serial tail between the chunk sums and AdamW, so it is written for latency: every chunk
+// sum and the chunk table are requested at once into LDS (one round trip to memory, where a wave per tensor used to
+// make two per tensor, six tensors in a row), the bias corrections, which do not depend on the norms, are worked out
+// by a thread of the last wave while those requests are in flight, and the sums over lanes stay on the vector ALU.
+constexpr int TN_LDS_CHUNKS = 4096;
 __global__ __launch_bounds__(1024) void tensor_norms_kernel(const double* __restrict__ chunk_ss,
                                                             const int* __restrict__ tensor_first_chunk, int ntensors,
-                                                            float* __restrict__ tnorm, float* __restrict__ out_sum,
-                                                            float* __restrict__ out_l2, const StepScalars sc) {
-  // one wave per tensor (16 waves take tensors round-robin), lanes stride over the tensor's chunk sums
+                                                            int nchunks, float* __restrict__ tnorm,
+                                                            float* __restrict__ out_sum, float* __restrict__ out_l2,
+                                                            const StepScalars sc) {
+  __shared__ double css[TN_LDS_CHUNKS];
+  __shared__ int first[1025];
   __shared__ float nrm[1024];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int t = w; t < ntensors; t += 16) {
-    double s = 0.0;
-    for (int c = tensor_first_chunk[t] + lane; c < tensor_first_chunk[t + 1]; c += 64) s += chunk_ss[c];
-    s = wave_sum_d(s);
-    if (lane == 0) {
-      const float v = (float)sqrt(s);
-      nrm[t] = v;
-      if (tnorm) tnorm[t] = v;
+  __shared__ float scal[3];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const bool staged = nchunks <= TN_LDS_CHUNKS;   // uniform
+  if (staged) {
+    double cv[TN_LDS_CHUNKS / 1024];
+#pragma unroll
+    for (int j = 0; j < TN_LDS_CHUNKS / 1024; ++j) cv[j] = chunk_ss[min(tid + j * 1024, nchunks - 1)];
+    const int f0 = tensor_first_chunk[min(tid, ntensors)];
+    const int f1 = tensor_first_chunk[ntensors];
+    if (sc.state && tid == 1023) {
+      const float t = sc.state[ST_STEP] + 1.f;
+      scal[0] = t;
+      scal[1] = (float)(1.0 - pow(sc.beta1, (double)t));
+      scal[2] = (float)sqrt(1.0 - pow(sc.beta2, (double)t));
+    }
+#pragma unroll
+    for (int j = 0; j < TN_LDS_CHUNKS / 1024; ++j)
+      if (tid + j * 1024 < nchunks) css[tid + j * 1024] = cv[j];
+    first[tid] = f0;
+    if (tid == 0) first[ntensors] = f1;
+    __syncthreads();
+    // one wave per tensor (16 waves take tensors round-robin), lanes stride over the tensor's chunk sums
+    for (int t = w; t < ntensors; t += 16) {
+      double s = 0.0;
+      for (int c = first[t] + lane; c < first[t + 1]; c += 64) s += css[c];
+      s = wave_sum_d(s);
+      if (lane == 0) {
+        const float v = (float)sqrt(s);
+        nrm[t] = v;
+        if (tnorm) tnorm[t] = v;
+      }
+    }
+  } else {
+    if (sc.state && tid == 1023) {
+      const float t = sc.state[ST_STEP] + 1.f;
+      scal[0] = t;
+      scal[1] = (float)(1.0 - pow(sc.beta1, (double)t));
+      scal[2] = (float)sqrt(1.0 - pow(sc.beta2, (double)t));
+    }
+    for (int t = w; t < ntensors; t += 16) {
+      double s = 0.0;
+      for (int c = tensor_first_chunk[t] + lane; c < tensor_first_chunk[t + 1]; c += 64) s += chunk_ss[c];
+      s = wave_sum_d(s);
+      if (lane == 0) {
+        const float v = (float)sqrt(s);
+        nrm[t] = v;
+        if (tnorm) tnorm[t] = v;
+      }
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float acc = 0.f;
+  if (w == 0) {
     double sq = 0.0;
-    for (int t = 0; t < ntensors; ++t) {
-      acc += nrm[t];
-      sq += (double)nrm[t] * (double)nrm[t];
+    for (int t = lane; t < ntensors; t += 64) sq += (double)nrm[t] * (double)nrm[t];
+    const float l2 = (float)sqrt(wave_sum_d(sq));
+    if (lane == 0) {
+      if (out_sum) {            // the regulariser's value: added up in registration order, as the reference's loop does
+        float acc = 0.f;
+        for (int t = 0; t < ntensors; ++t) acc += nrm[t];
+        out_sum[0] = acc;
+      }
+      if (out_l2) out_l2[0] = l2;
+      if (sc.state) {
+        sc.state[ST_STEP] = scal[0];
+        sc.state[ST_BC1] = scal[1];
+        sc.state[ST_BC2S] = scal[2];
+        sc.state[ST_CLIP] = sc.do_clip ? fminf(sc.max_norm / (l2 + 1e-6f), 1.f) : 1.f;
+      }
     }
-    if (out_sum) out_sum[0] = acc;
-    const float l2 = (float)sqrt(sq);
-    if (out_l2) out_l2[0] = l2;
-    if (sc.state) step_scalars(sc.state, sc.beta1, sc.beta2, sc.max_norm, sc.do_clip, l2);
   }
 }
 
@@ -299,8 +352,8 @@ MMSA_EXPORT int mmsa_param_norms(const float* p, const long long* chunk_off, con
   if (!chunk_sums_ready)   // otherwise chunk_ss already holds the sums (written by the previous mmsa_adamw_step)
     hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, p, (const float*)nullptr,
                        (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss, SparseRows{-1});
-  hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors, tnorm,
-                     sum_out, (float*)nullptr, StepScalars{});
+  hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors, nchunks,
+                     tnorm, sum_out, (float*)nullptr, StepScalars{});
   return mmsa_launch_status();
 }
 
@@ -325,7 +378,7 @@ MMSA_EXPORT int mmsa_grad_norm(const float* g, const float* p, const float* tnor
   hipStream_t s = mmsa_stream(stream);
   hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, g, p, tnorm, lambda, chunk_off, chunk_len,
                      chunk_tensor, chunk_ss, SparseRows{-1});
-  hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors,
+  hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors, nchunks,
                      (float*)nullptr, (float*)nullptr, state + ST_GNORM, StepScalars{});
   return mmsa_launch_status();
 }
@@ -355,7 +408,7 @@ MMSA_EXPORT int mmsa_grad_norm_finish(const float* g, const float* p, const floa
   hipStream_t s = mmsa_stream(stream);
   hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, g, p, tnorm, lambda, chunk_off, chunk_len,
                      chunk_tensor, chunk_ss, sp);
-  hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors,
+  hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors, nchunks,
                      (float*)nullptr, (float*)nullptr, state + ST_GNORM,
                      StepScalars{state, beta1, beta2, max_norm, do_clip});
   return mmsa_launch_status();
