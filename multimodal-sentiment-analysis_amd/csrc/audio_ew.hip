@@ -366,6 +366,10 @@ __device__ __forceinline__ void bn_finalize_body(const float* __restrict__ parti
   const float* ps = partial + (long)c * rows;
   const float* pq = partial + ((long)C + c) * rows;
   const bool stashed = training && bsum && rows <= STASH;   // uniform
+  // (what the last thread standing needs is requested ahead of the sums: behind their barriers it would be one more
+  // round trip to memory on a kernel that is nothing but latency)
+  const float gam = gamma[c], bet = beta[c];
+  const float rm0 = rmean ? rmean[c] : 0.f, rv0 = rmean ? rvar[c] : 0.f;
   double s = 0.0, q = 0.0;
   if (training) {
     for (int r = threadIdx.x; r < rows; r += 256) {
@@ -387,19 +391,19 @@ __device__ __forceinline__ void bn_finalize_body(const float* __restrict__ parti
       var = (float)v;
       if (rmean) {
         const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+        rmean[c] = (1.f - momentum) * rm0 + momentum * mean;
+        rvar[c] = (1.f - momentum) * rv0 + momentum * (float)unb;
       }
     } else {
-      mean = rmean[c];
-      var = rvar[c];
+      mean = rm0;
+      var = rv0;
     }
     const float istd = 1.0f / sqrtf(var + eps);
-    const float sc = gamma[c] * istd;
+    const float sc = gam * istd;
     coeff[c] = mean;
     coeff[C + c] = istd;
     coeff[2 * C + c] = sc;
-    coeff[3 * C + c] = beta[c] - mean * sc;
+    coeff[3 * C + c] = bet - mean * sc;
   }
   if (bsum) {
     // eight lanes per utterance: each takes every eighth tile, the eight sums meet through lane exchanges
@@ -1125,6 +1129,10 @@ __global__ __launch_bounds__(256) void bn_bwd_coeff_kernel(const float* __restri
   const int c = blockIdx.x;
   const float* p1 = partial + (long)c * rows;
   const float* p2 = partial + ((long)C + c) * rows;
+  // (what the last thread standing needs is requested ahead of the sums: behind their barriers it would be one more
+  // round trip to memory on a kernel that is nothing but latency)
+  float mean = 0.f, istd = 0.f, sc = 0.f;
+  if (cb) { mean = coeff[c]; istd = coeff[C + c]; sc = coeff[2 * C + c]; }
   double s = 0.0, q = 0.0;
   for (int r = threadIdx.x; r < rows; r += 256) {
     s += (double)p1[r];
@@ -1136,7 +1144,6 @@ __global__ __launch_bounds__(256) void bn_bwd_coeff_kernel(const float* __restri
     if (dbeta) dbeta[c] = (float)S1;
     if (s12) { s12[c] = (float)S1; s12[C + c] = (float)S2; }
     if (cb) {
-      const float mean = coeff[c], istd = coeff[C + c], sc = coeff[2 * C + c];
       const float m1 = training ? (float)(S1 / count) : 0.f, m2 = training ? (float)(S2 / count) : 0.f;
       cb[c] = sc;
       cb[C + c] = -sc * istd * m2;
