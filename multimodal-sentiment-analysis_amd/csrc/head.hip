@@ -975,8 +975,8 @@ constexpr size_t BWD_STAGED_LDS = (1024 * 3 + 512 + 4 * HT + SM_WATT + SM_W1 + S
 
 // Do the staged kernels' fixed pass counts and LDS regions hold these dimensions?
 bool staged_ok(const HeadDims& d) {
-  static const bool off = [] { const char* e = getenv("MMSA_HEAD_STAGED"); return e && e[0] == '0'; }();
-  if (off) return false;
+  const char* e = getenv("MMSA_HEAD_STAGED");   // 0: always the plain kernels (read at every launch: a test can switch)
+  if (e && e[0] == '0') return false;
   if (d.A > 256 || d.T > 384 || d.Hd > 256 || d.N0 > 128) return false;
   if (4 * d.Hd > SM_WATT || d.N0 * d.N1 > SM_W1 || d.N1 * d.C > SM_W2) return false;
   if (d.N1 > SM_SLOT || d.C > SM_SLOT) return false;            // (the other short vectors are bounded above)

@@ -242,6 +242,32 @@ def test_fused_head_equals_layer_by_layer_head(monkeypatch, drop):
         assert float((g0[k] - g1[k]).abs().max()) <= 2e-4 * scale + 1e-7, k
 
 
+@pytest.mark.parametrize("drop", [0.0, 0.4])
+def test_fused_head_staged_kernels_equal_plain_kernels(monkeypatch, drop):
+    """The fusion head's kernels that request their operands ahead of use (the reference's dimensions) and the plain
+    ones (any dimensions up to 512) run the same arithmetic stage by stage: logits, loss and every gradient agree to
+    rounding of the last place, with and without dropout (same masks: same seeds and element keys)."""
+    b = batch_tensors(3, 8, vocab=SMALL_VOCAB, device=DEV)
+    res = []
+    for staged in ("1", "0"):
+        monkeypatch.setenv("MMSA_HEAD_STAGED", staged)
+        m = seeded_model("both", vocab=SMALL_VOCAB, fusion_dropout=drop).to(DEV).train()
+        monkeypatch.setattr(m.fusion_layer, "draw_modality_dropout", lambda: (False, False))
+        m.__dict__["_seed_counter"] = 0
+        out = m(**model_inputs("both", b), labels=b["label"])
+        out["loss"].backward()
+        res.append((out["logits"].detach().clone(), float(out["loss"].detach()),
+                    {k: p.grad.detach().clone() for k, p in m.named_parameters()}))
+    (l0, loss0, g0), (l1, loss1, g1) = res
+    assert float((l0 - l1).abs().max()) <= 2e-6 * float(l1.abs().max())
+    assert abs(loss0 - loss1) < 1e-6
+    for k in g0:
+        if is_noise_grad("both", k):
+            continue
+        scale = float(g1[k].abs().max()) + 1e-8
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-5 * scale + 1e-8, k
+
+
 @pytest.mark.parametrize("B", [1, 5, 33])
 def test_eval_forward_odd_batch_sizes_and_padding_rows(B):
     """Batch sizes that are not multiples of anything the kernels tile by, a row of nothing but padding tokens and a
