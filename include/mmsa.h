@@ -240,6 +240,17 @@ MMSA_API int mmsa_resblock_bwd_ew_from_mean(const float* dfeat, const float* c2,
                                             float* d_c2, float* d_sc, float* dgamma2, float* dbeta2, float* dgammas,
                                             float* dbetas, float* dW1, float* dW2, float* scratch, int B, int H, int W,
                                             int C, int training, void* stream);
+/* mmsa_resblock_bwd_ew for a block with no pooling behind it -- ResidualBlock.forward used on its own, autograd of
+ * multimodal_model.py:64-70: dout is [B][H][W][C] (any H, W >= 2).  training: bit 0 batch statistics; bit 1 the shortcut
+ * is a fixed affine map whatever bit 0 says (the identity shortcut of :56-61 when the channel count stays: pass
+ * coeffs = [0, 1, 1, 0] per channel, dgammas / dbetas are then scratch) */
+MMSA_API long mmsa_resblock_bwd_unpooled_scratch_floats(int B, int H, int W, int C);
+MMSA_API int mmsa_resblock_bwd_ew_unpooled(const float* dout, const float* c2, const float* sc, const float* coeff2,
+                                           const float* coeffs, const float* gate, const float* hid, const float* gap,
+                                           const float* bsum, const float* W1, const float* W2, float* d_c2,
+                                           float* d_sc, float* dgamma2, float* dbeta2, float* dgammas, float* dbetas,
+                                           float* dW1, float* dW2, float* scratch, int B, int H, int W, int C,
+                                           int training, void* stream);
 /* dW1, dW2 may both be null in mmsa_resblock_bwd_ew: the squeeze-excite weight gradients are then left to this call
  * (same scratch and geometry), which can run on another stream since nothing but the optimiser reads them */
 MMSA_API int mmsa_resblock_bwd_se_wgrad(const float* scratch, const float* hid, const float* gap, float* dW1,

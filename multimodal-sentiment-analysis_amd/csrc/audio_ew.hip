@@ -793,7 +793,11 @@ __global__ __launch_bounds__(256) void res_pool_bwd_kernel(const float* __restri
   const int q = threadIdx.x % c4n, pl = threadIdx.x / c4n;
   const int c = q * 4;
   const int b = blockIdx.x / nchunks, ch = blockIdx.x - b * nchunks;
-  const int H2 = H / 2, W2 = W / 2, P2 = H2 * W2;
+  // dout_mean == 2: no pooling follows the block (a ResidualBlock used on its own): dout is [B][H][W][C] and every
+  // position with z > 0 takes its own gradient; the 2x2 windows then only serve as the unit of work and cover an odd
+  // last row / column too
+  const bool unpooled = dout_mean == 2;
+  const int H2 = unpooled ? (H + 1) / 2 : H / 2, W2 = unpooled ? (W + 1) / 2 : W / 2, P2 = H2 * W2;
   const f32x4 s2 = *reinterpret_cast<const f32x4*>(coeff2 + 2 * C + c);
   const f32x4 h2c = *reinterpret_cast<const f32x4*>(coeff2 + 3 * C + c);
   const f32x4 ss = *reinterpret_cast<const f32x4*>(coeffs + 2 * C + c);
@@ -805,23 +809,47 @@ __global__ __launch_bounds__(256) void res_pool_bwd_kernel(const float* __restri
     const int h2 = p2 / W2, w2 = p2 - h2 * W2;
     // dout_mean: dout is [B][C], the gradient with respect to the mean over the pooled positions (global average pool
     // behind the last block): every position's gradient is that value / P2
+    f32x4 av[4], sv[4];
+    long offs[4];
+    f32x4 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (unpooled) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int hh = 2 * h2 + (k >> 1), ww = 2 * w2 + (k & 1);
+        if (hh >= H || ww >= W) continue;
+        const long off = (((long)b * H + hh) * W + ww) * C + c;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(c2 + off);
+        const f32x4 sv1 = *reinterpret_cast<const f32x4*>(sc + off);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dout + off);
+        f32x4 ok = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = fmaf(fmaf(a[e], s2[e], h2c[e]), gt[e], fmaf(sv1[e], ss[e], hs[e]));
+          if (z > 0.f) {
+            ok[e] = g[e];
+            a1[e] += g[e];
+            a2[e] = fmaf(g[e], a[e], a2[e]);
+            a3[e] = fmaf(g[e], sv1[e], a3[e]);
+          }
+        }
+        *reinterpret_cast<f32x4*>(dz + off) = ok;
+      }
+      continue;
+    }
     f32x4 d = *reinterpret_cast<const f32x4*>(dout + (dout_mean ? (long)b * C : ((long)b * P2 + p2) * C) + c);
     if (dout_mean) {
       const float inv = 1.0f / (float)P2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] *= inv;
     }
-    f32x4 av[4], sv[4];
-    long offs[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       offs[k] = (((long)b * H + 2 * h2 + (k >> 1)) * W + 2 * w2 + (k & 1)) * C + c;
       av[k] = *reinterpret_cast<const f32x4*>(c2 + offs[k]);
       sv[k] = *reinterpret_cast<const f32x4*>(sc + offs[k]);
     }
-    f32x4 o[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) o[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float best = -INFINITY;
@@ -1006,8 +1034,11 @@ __global__ __launch_bounds__(256) void rb_bwd_coeff_kernel(const float* __restri
   }
   const float n = (float)B * hw;
   // in eval mode BatchNorm is a fixed affine map: only the scale survives
-  const float m1 = training ? (float)S1 / n : 0.f, m2 = training ? (float)S2 / n : 0.f;
-  const float m1s = training ? (float)S1s / n : 0.f, m2s = training ? (float)S2s / n : 0.f;
+  // (training bit 1: the shortcut is a fixed affine map whatever bn2 is -- the identity shortcut of a block whose
+  // channel count stays, which has no BatchNorm)
+  const bool train2 = training & 1, train_s = train2 && !(training & 2);
+  const float m1 = train2 ? (float)S1 / n : 0.f, m2 = train2 ? (float)S2 / n : 0.f;
+  const float m1s = train_s ? (float)S1s / n : 0.f, m2s = train_s ? (float)S2s / n : 0.f;
   float* P = tab;
   float* R = tab + (long)B * C;
   float* Q = tab + 2L * B * C;
@@ -1360,6 +1391,26 @@ static int rb_bwd_chunk(int B, int P2, int planes) {
   return planes * passes;
 }
 
+// windows of the element-wise backward's first pass: 2x2 pooling windows, or (a block without pooling behind it) 2x2
+// units of work that also cover an odd last row / column
+static int rb_bwd_windows(int H, int W, bool unpooled) {
+  return unpooled ? ((H + 1) / 2) * ((W + 1) / 2) : (H / 2) * (W / 2);
+}
+
+static long rb_bwd_scratch(int B, int H, int W, int C, bool unpooled) {
+  if (B <= 0 || H < 2 || W < 2 || C < 64 || C > 256 || C % 64) return MMSA_ERR_ARG;
+  const int P2 = rb_bwd_windows(H, W, unpooled);
+  const int planes = 1024 / C, chunk = rb_bwd_chunk(B, P2, planes);
+  const int nchunks = (P2 + chunk - 1) / chunk;
+  const int Ch = C / 16;
+  // partial[B][nchunks][3][C] + A[B][3][C] + du[B][C] + dhp[B][Ch] + dg[B][C] + tab[2*B*C + 4*C]
+  return (long)B * nchunks * 3 * C + (long)B * 3 * C + (long)B * C + (long)B * Ch + (long)B * C + 2L * B * C + 4L * C;
+}
+
+MMSA_EXPORT long mmsa_resblock_bwd_unpooled_scratch_floats(int B, int H, int W, int C) {
+  return rb_bwd_scratch(B, H, W, C, true);
+}
+
 MMSA_EXPORT long mmsa_resblock_bwd_scratch_floats(int B, int H, int W, int C) {
   if (B <= 0 || H < 2 || W < 2 || C < 64 || C > 256 || C % 64) return MMSA_ERR_ARG;
   const int planes = 1024 / C, chunk = rb_bwd_chunk(B, (H / 2) * (W / 2), planes);
@@ -1382,8 +1433,8 @@ static int resblock_bwd_ew_impl(const float* dout, int dout_mean, const float* c
   MMSA_REQUIRE(dgamma2 && dbeta2 && dgammas && dbetas && scratch && (dW1 != nullptr) == (dW2 != nullptr));
   MMSA_REQUIRE(B > 0 && H >= 2 && W >= 2 && C >= 64 && C <= 256 && C % 64 == 0);
   hipStream_t s = mmsa_stream(stream);
-  const int planes = 1024 / C, chunk = rb_bwd_chunk(B, (H / 2) * (W / 2), planes);
-  const int P2 = (H / 2) * (W / 2);
+  const int P2 = rb_bwd_windows(H, W, dout_mean == 2);
+  const int planes = 1024 / C, chunk = rb_bwd_chunk(B, P2, planes);
   const int nchunks = (P2 + chunk - 1) / chunk;
   const int Ch = C / 16;
   float* partial = scratch;
@@ -1430,6 +1481,21 @@ MMSA_EXPORT int mmsa_resblock_bwd_ew_from_mean(const float* dfeat, const float* 
                                                int W, int C, int training, void* stream) {
   return resblock_bwd_ew_impl(dfeat, 1, c2, sc, coeff2, coeffs, gate, hid, gap, bsum, W1, W2, d_c2, d_sc, dgamma2,
                               dbeta2, dgammas, dbetas, dW1, dW2, scratch, B, H, W, C, training, stream);
+}
+
+// The same for a residual block with no pooling behind it (the reference's ResidualBlock used on its own,
+// multimodal_model.py:64-70): dout is [B][H][W][C], any H, W >= 2.  training: bit 0 batch statistics, bit 1 the
+// shortcut is a fixed affine map whatever bit 0 says (coeffs = [0, 1, 1, 0] per channel for the identity shortcut
+// of a block whose channel count stays; dgammas / dbetas are then scratch).  Scratch:
+// mmsa_resblock_bwd_unpooled_scratch_floats.
+MMSA_EXPORT int mmsa_resblock_bwd_ew_unpooled(const float* dout, const float* c2, const float* sc, const float* coeff2,
+                                              const float* coeffs, const float* gate, const float* hid,
+                                              const float* gap, const float* bsum, const float* W1, const float* W2,
+                                              float* d_c2, float* d_sc, float* dgamma2, float* dbeta2, float* dgammas,
+                                              float* dbetas, float* dW1, float* dW2, float* scratch, int B, int H,
+                                              int W, int C, int training, void* stream) {
+  return resblock_bwd_ew_impl(dout, 2, c2, sc, coeff2, coeffs, gate, hid, gap, bsum, W1, W2, d_c2, d_sc, dgamma2, dbeta2,
+                              dgammas, dbetas, dW1, dW2, scratch, B, H, W, C, training, stream);
 }
 
 // Gradients of the two squeeze-excite matrices from the scratch mmsa_resblock_bwd_ew left behind (same geometry,

@@ -51,15 +51,25 @@ def _stack(spec) -> nn.Sequential:
     return nn.Sequential(*[makers[s[0]](*s[1:]) for s in spec])
 
 
-def _standalone_no_grad(module: nn.Module, name: str, *inputs):
-    """The stand-alone forward of a sub-module is a HIP launch sequence without an autograd node: its backward lives in
-    the parent's launch sequence (AudioModel / TextModel / MultimodalSentimentModel).  Rather than hand back a tensor
-    that silently carries no gradient, refuse when one is asked for."""
-    if torch.is_grad_enabled() and (any(p.requires_grad for p in module.parameters())
-                                    or any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs)):
-        raise RuntimeError(f"{name}.forward on its own runs without autograd (wrap the call in torch.no_grad()); "
-                           "gradients flow through AudioModel / TextModel / MultimodalSentimentModel, whose backward "
-                           "is the fused HIP sequence")
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the HIP dense kernel, with its backward (rows of x: [n, K])."""
+
+    @staticmethod
+    def forward(ctx, rows, weight, bias):
+        y = torch.empty((rows.shape[0], weight.shape[0]), dtype=torch.float32, device=rows.device)
+        ops.dense_fwd(rows, weight, bias, None, None, y, None, None, ops.EPI_NONE)
+        ctx.save_for_backward(rows, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dpre = torch.empty_like(dy)
+        dx = torch.empty_like(rows)
+        dW, db = torch.empty_like(weight), torch.empty(weight.shape[0], dtype=torch.float32, device=dy.device)
+        ops.dense_bwd(dy, rows, None, None, weight, None, None, dpre, None, dx, dW, db, None, None, ops.EPI_NONE)
+        return dx, dW, db
 
 
 def _channels_last(x: torch.Tensor, dev) -> torch.Tensor:
@@ -80,14 +90,11 @@ class Attention(nn.Module):
 
     def forward(self, x):
         dev = _require_gpu(self, "Attention")
-        _standalone_no_grad(self, "Attention", x)
         x = x.to(device=dev, dtype=torch.float32)
         rows = x.reshape(-1, x.shape[-1]).contiguous()
 
         def proj(lin):
-            y = torch.empty((rows.shape[0], lin.weight.shape[0]), dtype=torch.float32, device=dev)
-            ops.dense_fwd(rows, lin.weight, lin.bias, None, None, y, None, None, ops.EPI_NONE)
-            return y.reshape(*x.shape[:-1], -1)
+            return _LinearFn.apply(rows, lin.weight, lin.bias).reshape(*x.shape[:-1], -1)
         q, k, v = proj(self.query), proj(self.key), proj(self.value)
         attn = torch.softmax(torch.matmul(q, k.transpose(-2, -1)) / self.scale, dim=-1)
         return torch.matmul(attn, v)
@@ -105,15 +112,26 @@ class SEBlock(nn.Module):
 
     def forward(self, x):
         dev = _require_gpu(self, "SEBlock")
-        _standalone_no_grad(self, "SEBlock", x)
         W1, W2 = self.fc[0].weight, self.fc[2].weight
         Ch, C = W1.shape
         if C > 256 or Ch > 16 or C % 4 or Ch < 1:
             raise NotImplementedError("the HIP squeeze-excite kernel takes up to 256 channels and 16 hidden units")
         xl = _channels_last(x, dev)
-        B, H, W, _ = xl.shape
         if xl.shape[3] != C:
             raise ValueError(f"SEBlock({C}) got {xl.shape[3]} channels")
+        return _SEBlockFn.apply(xl, W1, W2).permute(0, 3, 1, 2)
+
+
+class _SEBlockFn(torch.autograd.Function):
+    """SEBlock on its own (channels-last in and out).  Forward: three HIP launches.  Backward: the map-sized work
+    (dout * gate) is a HIP launch; the per-utterance [B, C] / [B, C/r] algebra of the two small matrices, a few
+    thousand multiply-adds, is left to torch's GPU operators."""
+
+    @staticmethod
+    def forward(ctx, xl, W1, W2):
+        dev = xl.device
+        B, H, W, C = xl.shape
+        Ch = W1.shape[0]
         K = torch.ops.mmsa
         mean = torch.empty((B, C), dtype=torch.float32, device=dev)
         K.gap_fwd(xl, mean, B, H * W, C)
@@ -123,7 +141,24 @@ class SEBlock(nn.Module):
         K.se_gate(mean, ident, W1, W2, 1, gap, hid, gate, B, C)
         out = torch.empty_like(xl)
         K.gate_affine_add(xl, None, gate, None, None, out, B, H * W, C, False)
-        return out.permute(0, 3, 1, 2)
+        ctx.save_for_backward(xl, gap, hid, gate, W1, W2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xl, gap, hid, gate, W1, W2 = ctx.saved_tensors
+        B, H, W, C = xl.shape
+        dout = dout.contiguous()
+        dgate = (dout * xl).sum(dim=(1, 2))                      # [B, C]
+        du = dgate * gate * (1.0 - gate)                          # through the sigmoid
+        dW2 = du.t() @ hid                                        # [C, Ch]
+        dhid = (du @ W2) * (hid > 0)                              # through the ReLU
+        dW1 = dhid.t() @ gap                                      # [Ch, C]
+        dgap = dhid @ W1                                          # [B, C]
+        dx = torch.empty_like(xl)
+        torch.ops.mmsa.gate_affine_add(dout, None, gate, None, None, dx, B, H * W, C, False)
+        dx += (dgap / float(H * W)).view(B, 1, 1, C)
+        return dx, dW1, dW2
 
 
 class ResidualBlock(nn.Module):
@@ -146,25 +181,44 @@ class ResidualBlock(nn.Module):
 
     def forward(self, x):
         dev = _require_gpu(self, "ResidualBlock")
-        _standalone_no_grad(self, "ResidualBlock", x)
         if self.stride != 1:
             raise NotImplementedError("the HIP convolution kernels are stride 1 (what the model uses)")
         Cout, Cin = self.conv1.weight.shape[:2]
         if Cin % 32 or Cout % 64 or Cout > 256:
             raise NotImplementedError("HIP residual block: in_channels % 32 == 0, out_channels % 64 == 0 and <= 256")
         xl = _channels_last(x, dev)
-        B, H, W, _ = xl.shape
         if xl.shape[3] != Cin:
             raise ValueError(f"ResidualBlock expects {Cin} channels, got {xl.shape[3]}")
-        K = torch.ops.mmsa
-        training = self.training
-        project = len(self.shortcut) > 0
-        npos = B * H * W
+        need_grad = torch.is_grad_enabled() and (xl.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if need_grad:
+            B, H, W, _ = xl.shape
+            if H < 2 or W < 2 or not ops.conv_wgrad_supported(B, H, W, Cin, Cout):
+                raise NotImplementedError("ResidualBlock backward: the map is too small or too wide for the "
+                                          "weight-gradient kernels (rows of at most about 238 positions)")
+        return _ResidualBlockFn.apply(self, xl, need_grad, *self.parameters()).permute(0, 3, 1, 2)
 
-        def conv_bn(conv, bn, X, cin, taps, want_bsum):
+
+class _ResidualBlockFn(torch.autograd.Function):
+    """ResidualBlock on its own (channels-last in and out): the launch sequence the audio branch uses for a block, minus
+    the pooling that follows a block there; forward and backward are HIP launches throughout."""
+
+    @staticmethod
+    def forward(ctx, m, xl, need_grad, *params):
+        dev = xl.device
+        B, H, W, Cin = xl.shape
+        Cout = m.conv1.weight.shape[0]
+        K = torch.ops.mmsa
+        training = m.training
+        project = len(m.shortcut) > 0
+        npos = B * H * W
+        packs = {}
+
+        def conv_bn(tag, conv, bn, X, cin, taps, want_bsum):
             """conv (+ statistics epilogue) and the BatchNorm coefficient kernel; returns (raw map, coeff, bsum)."""
             wp = torch.empty(conv.weight.numel(), dtype=torch.float32, device=dev)
-            K.conv_pack_weights(conv.weight, wp, None)
+            wd = torch.empty(conv.weight.numel(), dtype=torch.float32, device=dev) if need_grad else None
+            K.conv_pack_weights(conv.weight, wp, wd)
+            packs[tag] = wd
             Y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
             rows, tiles = ops.conv_stats_rows(B, H, W, Cout)
             stats = torch.empty(rows * 2 * Cout, dtype=torch.float32, device=dev) if (training or want_bsum) else None
@@ -175,20 +229,71 @@ class ResidualBlock(nn.Module):
                           bn.num_batches_tracked, training, coeff, bsum, Cout)
             return Y, coeff, bsum
 
-        c1, coeff1, _ = conv_bn(self.conv1, self.bn1, xl, Cin, ops.TAPS3X3, False)
+        c1, coeff1, _ = conv_bn("c1", m.conv1, m.bn1, xl, Cin, ops.TAPS3X3, False)
         h1 = torch.empty_like(c1)
         K.bn_relu_apply(c1, coeff1, h1, npos, Cout)
-        c2, coeff2, bsum2 = conv_bn(self.conv2, self.bn2, h1, Cout, ops.TAPS3X3, True)
-        W1, W2 = self.se.fc[0].weight, self.se.fc[2].weight
+        c2, coeff2, bsum2 = conv_bn("c2", m.conv2, m.bn2, h1, Cout, ops.TAPS3X3, True)
+        W1, W2 = m.se.fc[0].weight, m.se.fc[2].weight
         gap, hid, gate = (torch.empty((B, n), dtype=torch.float32, device=dev) for n in (Cout, W1.shape[0], Cout))
         K.se_gate(bsum2, coeff2, W1, W2, H * W, gap, hid, gate, B, Cout)
         if project:
-            sc, coeffs, _ = conv_bn(self.shortcut[0], self.shortcut[1], xl, Cin, ops.TAPS1X1, False)
+            sc, coeffs, _ = conv_bn("sc", m.shortcut[0], m.shortcut[1], xl, Cin, ops.TAPS1X1, False)
         else:
             sc, coeffs = xl, None
         out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=dev)
         K.gate_affine_add(c2, coeff2, gate, sc, coeffs, out, B, H * W, Cout, True)
-        return out.permute(0, 3, 1, 2)
+        if need_grad:
+            ctx.m = m
+            ctx.st = (xl, c1, coeff1, h1, c2, coeff2, bsum2, gap, hid, gate, sc, coeffs, packs, training, project)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        m = ctx.m
+        xl, c1, coeff1, h1, c2, coeff2, bsum2, gap, hid, gate, sc, coeffs, packs, training, project = ctx.st
+        dev = xl.device
+        B, H, W, Cin = xl.shape
+        Cout = c2.shape[3]
+        npos = B * H * W
+        f32 = dict(dtype=torch.float32, device=dev)
+        grads = Grads()
+        W1, W2 = m.se.fc[0].weight, m.se.fc[2].weight
+        if project:
+            bns = m.shortcut[1]
+            dgs, dbs = grads.of(bns.weight), grads.of(bns.bias)
+            flags = int(training)
+        else:
+            # identity shortcut: a fixed affine map with scale 1 (multimodal_model.py:56-61 leaves the Sequential empty)
+            coeffs = torch.zeros(4 * Cout, **f32)
+            coeffs[Cout:3 * Cout] = 1.0
+            dgs, dbs = torch.empty(Cout, **f32), torch.empty(Cout, **f32)
+            flags = int(training) | 2
+        d_c2 = torch.empty((B, H, W, Cout), **f32)
+        d_sc = torch.empty((B, H, W, Cout), **f32)
+        scratch = torch.empty(ops.resblock_bwd_scratch(B, H, W, Cout, unpooled=True), **f32)
+        ops.resblock_bwd_ew(dout.contiguous(), c2, sc, coeff2, coeffs, gate, hid, gap, bsum2, W1, W2, d_c2, d_sc,
+                            grads.of(m.bn2.weight), grads.of(m.bn2.bias), dgs, dbs, grads.of(W1), grads.of(W2), scratch,
+                            B, H, W, Cout, flags, unpooled=True)
+        wsz = max(ops.conv_wgrad_workspace(B, H, W, Cout, Cout, 9), ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 9),
+                  ops.conv_wgrad_workspace(B, H, W, Cin, Cout, 1))
+        wbuf = torch.empty(wsz, **f32)
+        # second convolution: data gradient (flipped taps), weight gradient, then through ReLU and bn1 in place
+        d_h1 = torch.empty((B, H, W, Cout), **f32)
+        ops.conv_fwd(d_c2, packs["c2"], d_h1, None, B, H, W, Cout, Cout, ops.TAPS3X3, negate=True)
+        ops.conv_wgrad(h1, d_c2, grads.of(m.conv2.weight), wbuf, B, H, W, Cout, Cout, ops.TAPS3X3)
+        ops.bn_relu_bwd(d_h1, c1, coeff1, grads.of(m.bn1.weight), grads.of(m.bn1.bias),
+                        torch.empty(ops.bn_relu_bwd_scratch(npos, Cout), **f32), npos, Cout, training)
+        d_c1 = d_h1
+        # first convolution and the shortcut
+        d_in = torch.empty((B, H, W, Cin), **f32)
+        if project:
+            ops.conv_fwd_dual(d_c1, packs["c1"], d_sc, packs["sc"], d_in, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
+            ops.conv_wgrad(xl, d_sc, grads.of(m.shortcut[0].weight), wbuf, B, H, W, Cin, Cout, ops.TAPS1X1)
+        else:
+            ops.conv_fwd(d_c1, packs["c1"], d_in, None, B, H, W, Cout, Cin, ops.TAPS3X3, negate=True)
+            d_in += d_sc
+        ops.conv_wgrad(xl, d_c1, grads.of(m.conv1.weight), wbuf, B, H, W, Cin, Cout, ops.TAPS3X3)
+        return (None, d_in, None) + tuple(grads.of(p, zero=True) for p in m.parameters())
 
 
 def _require_gpu(module: nn.Module, what: str):
@@ -310,18 +415,48 @@ class MultifactorFeatureNormalizer(nn.Module):
     def forward(self, audio_features, text_features):
         """multimodal_model.py:216-225: (LayerNorm(audio) * audio_scale, LayerNorm(text) * text_scale)."""
         dev = _require_gpu(self, "MultifactorFeatureNormalizer")
-        _standalone_no_grad(self, "MultifactorFeatureNormalizer", audio_features, text_features)
-        outs = []
-        for x, norm, scale in ((audio_features, self.audio_norm, self.audio_scale),
-                               (text_features, self.text_norm, self.text_scale)):
+        xs = []
+        for x, norm in ((audio_features, self.audio_norm), (text_features, self.text_norm)):
             x = x.to(device=dev, dtype=torch.float32).contiguous()
             if x.dim() != 2 or x.shape[1] != norm.weight.shape[0]:
                 raise ValueError("features must be [B, dim] with the dims the normaliser was built for")
+            xs.append(x)
+        return _NormalizerFn.apply(self, xs[0], xs[1], *self.parameters())
+
+
+class _NormalizerFn(torch.autograd.Function):
+    """The feature normaliser on its own: two `ln_scale` launches forward, two backward."""
+
+    @staticmethod
+    def forward(ctx, m, a, t, *params):
+        outs, saved = [], []
+        for x, norm, scale in ((a, m.audio_norm, m.audio_scale), (t, m.text_norm, m.text_scale)):
             y = torch.empty_like(x)
-            stats = torch.empty(2 * x.shape[0], dtype=torch.float32, device=dev)
-            torch.ops.mmsa.ln_scale_fwd(x, norm.weight, norm.bias, scale, None, y, stats)
+            stats = torch.empty(2 * x.shape[0], dtype=torch.float32, device=x.device)
+            ops.ln_scale_fwd(x, norm.weight, norm.bias, scale, None, y, stats)
             outs.append(y)
+            saved += [x, stats]
+        ctx.m = m
+        ctx.save_for_backward(*saved)
         return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, dya, dyt):
+        m = ctx.m
+        xa, sa, xt, st = ctx.saved_tensors
+        grads = {}
+        dxs = []
+        for dy, x, stats, norm, scale in ((dya, xa, sa, m.audio_norm, m.audio_scale),
+                                          (dyt, xt, st, m.text_norm, m.text_scale)):
+            B, N = x.shape
+            dy = torch.zeros_like(x) if dy is None else dy.contiguous()
+            dx = torch.empty_like(x)
+            dg, db, ds = torch.empty_like(norm.weight), torch.empty_like(norm.bias), torch.empty_like(scale)
+            ops.ln_scale_bwd(dy, x, norm.weight, norm.bias, scale, None, stats, dx, dg, db, ds,
+                             torch.empty(B * N + B, dtype=torch.float32, device=x.device))
+            dxs.append(dx)
+            grads[id(norm.weight)], grads[id(norm.bias)], grads[id(scale)] = dg, db, ds
+        return (None, dxs[0], dxs[1]) + tuple(grads[id(p)] for p in m.parameters())
 
 
 class ModalityFusion(nn.Module):
@@ -349,32 +484,62 @@ class ModalityFusion(nn.Module):
         """multimodal_model.py:263-285: modality dropout (two host draws, training only), the two projectors
         (Linear -> LayerNorm -> ReLU -> Dropout), the two-way attention softmax and the weighted sum."""
         dev = _require_gpu(self, "ModalityFusion")
-        _standalone_no_grad(self, "ModalityFusion", audio_features, text_features)
         a = audio_features.to(device=dev, dtype=torch.float32).contiguous()
         t = text_features.to(device=dev, dtype=torch.float32).contiguous()
         da, dt = self.draw_modality_dropout()
-        if da:
-            a = torch.zeros_like(a)
-        if dt:
-            t = torch.zeros_like(t)
-        B = a.shape[0]
-        Hd = self.output_dim
         p = self.audio_projector[3].p if self.training else 0.0
         seed = (torch.initial_seed() * 1000003 + int(torch.randint(0, 2 ** 31, (1,)).item())) & ((1 << 62) - 1) if p > 0 else 0
+        return _FusionFn.apply(self, a, t, bool(da), bool(dt), float(p), int(seed), *self.parameters())
+
+
+class _FusionFn(torch.autograd.Function):
+    """The fusion layer on its own: the launch sequence of the layer-by-layer head (dense kernels with the
+    LayerNorm + ReLU + dropout epilogue, the two-way softmax mix) and its backward."""
+
+    @staticmethod
+    def forward(ctx, m, a, t, drop_a, drop_t, p, seed, *params):
+        from .head import _Dense
+        dev = a.device
+        ws = Workspace(dev, persistent=False)
+        if drop_a:
+            a = torch.zeros_like(a)
+        if drop_t:
+            t = torch.zeros_like(t)
+        B, Hd = a.shape[0], m.output_dim
         P = torch.empty((B, 2 * Hd), dtype=torch.float32, device=dev)
-        for x, proj, col, sd in ((a, self.audio_projector, 0, seed), (t, self.text_projector, Hd, seed + 1)):
-            lin, norm = proj[0], proj[1]
-            pre = torch.empty((B, Hd), dtype=torch.float32, device=dev)
-            stats = torch.empty(2 * B, dtype=torch.float32, device=dev)
-            torch.ops.mmsa.dense_fwd(x, lin.weight, lin.bias, norm.weight, norm.bias, P[:, col:col + Hd], pre, stats,
-                                     ops.EPI_LN_RELU, p, sd)
-        att = torch.empty((B, 2), dtype=torch.float32, device=dev)
-        torch.ops.mmsa.dense_fwd(P, self.attention[0].weight, self.attention[0].bias, None, None, att, None, None,
-                                 ops.EPI_NONE)
+        pa = _Dense(ws, "pa", m.audio_projector[0], m.audio_projector[1], ops.EPI_LN_RELU, B, p, seed)
+        pt = _Dense(ws, "pt", m.text_projector[0], m.text_projector[1], ops.EPI_LN_RELU, B, p, seed + 1)
+        pa.fwd(a, P[:, :Hd])
+        pt.fwd(t, P[:, Hd:])
+        att = _Dense(ws, "att", m.attention[0], None, ops.EPI_NONE, B)
+        att_out = att.fwd(P, torch.empty((B, 2), dtype=torch.float32, device=dev))
         wts = torch.empty(2 * B, dtype=torch.float32, device=dev)
         fused = torch.empty((B, Hd), dtype=torch.float32, device=dev)
-        torch.ops.mmsa.fusion_mix_fwd(P, att, wts, fused)
+        ops.fusion_mix_fwd(P, att_out, wts, fused)
+        ctx.m, ctx.st = m, (ws, pa, pt, att, P, wts, drop_a, drop_t)
         return fused
+
+    @staticmethod
+    def backward(ctx, dfused):
+        m = ctx.m
+        ws, pa, pt, att, P, wts, drop_a, drop_t = ctx.st
+        B, Hd = P.shape[0], m.output_dim
+        dev = P.device
+        grads = Grads()
+        dP = torch.empty_like(P)
+        datt = torch.empty((B, 2), dtype=torch.float32, device=dev)
+        ops.fusion_mix_bwd(dfused.contiguous(), P, wts, dP, datt)
+        att.bwd(ws, datt, dP, grads, accumulate_dx=True)
+        d_a = torch.empty((B, pa.K), dtype=torch.float32, device=dev)
+        d_t = torch.empty((B, pt.K), dtype=torch.float32, device=dev)
+        pa.bwd(ws, dP[:, :Hd], d_a, grads)
+        pt.bwd(ws, dP[:, Hd:], d_t, grads)
+        # a dropped modality's features were replaced by zeros (multimodal_model.py:269-273): no gradient reaches them
+        if drop_a:
+            d_a.zero_()
+        if drop_t:
+            d_t.zero_()
+        return (None, d_a, d_t, None, None, None, None) + tuple(grads.of(q, zero=True) for q in m.parameters())
 
 
 class _ModelFn(torch.autograd.Function):

@@ -587,16 +587,20 @@ def gap_bwd(dout, dx, B, P, C):
     _lib.call("mmsa_gap_bwd", _chk(dout), _chk(dx), B, P, C, _stream())
 
 
-def resblock_bwd_scratch(B, H, W, C) -> int:
-    return _lib.query("mmsa_resblock_bwd_scratch_floats", B, H, W, C)
+def resblock_bwd_scratch(B, H, W, C, unpooled=False) -> int:
+    return _lib.query("mmsa_resblock_bwd_unpooled_scratch_floats" if unpooled else "mmsa_resblock_bwd_scratch_floats",
+                      B, H, W, C)
 
 
 def resblock_bwd_ew(dout, c2, sc, coeff2, coeffs, gate, hid, gap, bsum, W1, W2, d_c2, d_sc, dgamma2, dbeta2,
-                    dgammas, dbetas, dW1, dW2, scratch, B, H, W, C, training, dout_is_mean=False):
-    """dout_is_mean: dout is [B, C], the gradient with respect to the mean of the block's pooled output."""
+                    dgammas, dbetas, dW1, dW2, scratch, B, H, W, C, training, dout_is_mean=False, unpooled=False):
+    """dout_is_mean: dout is [B, C], the gradient with respect to the mean of the block's pooled output.
+    unpooled: no pooling follows the block, dout is [B, H, W, C]; ``training`` may then carry bit 1 (= 2): the shortcut
+    is a fixed affine map (the identity shortcut, with coeffs = [0, 1, 1, 0] per channel)."""
     n = B * H * W * C
-    if dout.numel() != (B * C if dout_is_mean else B * (H // 2) * (W // 2) * C) or c2.numel() != n or sc.numel() != n or d_c2.numel() != n \
-            or d_sc.numel() != n or scratch.numel() < resblock_bwd_scratch(B, H, W, C):
+    want = n if unpooled else (B * C if dout_is_mean else B * (H // 2) * (W // 2) * C)
+    if dout.numel() != want or c2.numel() != n or sc.numel() != n or d_c2.numel() != n \
+            or d_sc.numel() != n or scratch.numel() < resblock_bwd_scratch(B, H, W, C, unpooled):
         raise ValueError("resblock_bwd_ew: bad sizes")
     for t in (dgamma2, dbeta2, dgammas, dbetas):
         if t.numel() != C:
@@ -605,7 +609,9 @@ def resblock_bwd_ew(dout, c2, sc, coeff2, coeffs, gate, hid, gap, bsum, W1, W2, 
         raise ValueError("resblock_bwd_ew: pass both SE gradients or neither")
     if dW1 is not None and (dW1.numel() != W1.numel() or dW2.numel() != W2.numel()):
         raise ValueError("resblock_bwd_ew: bad SE gradient size")
-    _lib.call("mmsa_resblock_bwd_ew_from_mean" if dout_is_mean else "mmsa_resblock_bwd_ew", _chk(dout), _chk(c2), _chk(sc), _chk(coeff2), _chk(coeffs), _chk(gate),
+    entry = ("mmsa_resblock_bwd_ew_unpooled" if unpooled else
+             "mmsa_resblock_bwd_ew_from_mean" if dout_is_mean else "mmsa_resblock_bwd_ew")
+    _lib.call(entry, _chk(dout), _chk(c2), _chk(sc), _chk(coeff2), _chk(coeffs), _chk(gate),
               _chk(hid), _chk(gap), _chk(bsum), _chk(W1), _chk(W2), _chk(d_c2), _chk(d_sc), _chk(dgamma2),
               _chk(dbeta2), _chk(dgammas), _chk(dbetas), _opt(dW1), _opt(dW2), _chk(scratch), B, H, W, C,
               int(training), _stream())

@@ -21,6 +21,12 @@ def _close(got, want, tol=1e-4):
     assert err < tol * max(1.0, float(want.abs().max())), err
 
 
+def _grad_close(got, want, tol=2e-4):
+    assert got is not None and want is not None and got.shape == want.shape
+    err = float((got.detach().cpu().double() - want.double()).abs().max())
+    assert err <= tol * float(want.abs().max()) + 1e-6, (err, float(want.abs().max()))   # (1e-6: gradients that are rounding noise around an analytic zero)
+
+
 def test_operators_are_registered_and_have_no_cpu_path():
     from mmsa_amd import torch_ops
     assert len(torch_ops.REGISTERED) >= 25
@@ -50,8 +56,16 @@ def test_se_block_alone(C, red):
     with torch.no_grad():
         got = m(x.to(DEV))
     _close(got, model_ref.se_block(_sd(m, "se"), "se", x))
-    with pytest.raises(RuntimeError, match="no_grad"):
-        m(x.to(DEV))                       # parameters require grad and autograd is on
+    # autograd through the block on its own: input and weight gradients against the oracle's
+    sd = model_ref.clone_state(_sd(m, "se"), requires_grad=True)
+    xr = x.clone().requires_grad_(True)
+    R = torch.randn(3, C, 8, 10)
+    (model_ref.se_block(sd, "se", xr) * R).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    (m(xg) * R.to(DEV)).sum().backward()
+    _grad_close(xg.grad, xr.grad)
+    for k, p in m.named_parameters():
+        _grad_close(p.grad, sd["se." + k].grad)
 
 
 @pytest.mark.parametrize("cin,cout,training", [(32, 64, True), (64, 128, False), (64, 64, True), (128, 128, False)])
@@ -85,6 +99,42 @@ def test_residual_block_alone(cin, cout, training):
             ResidualBlock(32, 64, stride=2).to(DEV)(x[:, :32].to(DEV))
 
 
+@pytest.mark.parametrize("cin,cout,training,hw", [(32, 64, True, (8, 12)), (64, 64, True, (7, 9)), (64, 128, False, (8, 12)),
+                                                   (128, 128, True, (6, 10)), (128, 256, True, (5, 8))])
+def test_residual_block_alone_backward(cin, cout, training, hw):
+    """loss.backward() through a ResidualBlock used on its own (the reference's blocks are ordinary differentiable
+    modules, multimodal_model.py:45-70): gradient of a random linear functional of the output with respect to the input
+    and to every parameter, against autograd through the oracle in double precision.  Projection and identity
+    shortcut, batch and running statistics, even and odd map sizes."""
+    from mmsa_amd.model import ResidualBlock
+    torch.manual_seed(cin * 3 + cout)
+    m = ResidualBlock(cin, cout).to(DEV).train(training)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if "se.fc" in k:
+                p.normal_(0, 0.3)
+            elif "bn" in k or k.startswith("shortcut.1"):
+                p.normal_(1.0 if k.endswith("weight") else 0.0, 0.3)
+        for k, b in m.named_buffers():
+            if k.endswith("running_mean"):
+                b.normal_(0, 0.2)
+            elif k.endswith("running_var"):
+                b.uniform_(0.5, 1.5)
+    H, W = hw
+    x = torch.randn(4, cin, H, W)
+    R = torch.randn(4, cout, H, W)
+    sd = {k: v.double() if v.is_floating_point() else v for k, v in _sd(m, "rb").items()}
+    sd = model_ref.clone_state(sd, requires_grad=True)
+    xr = x.double().requires_grad_(True)
+    (model_ref.residual_block(sd, "rb", xr, training) * R.double()).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    out = m(xg)
+    (out * R.to(DEV)).sum().backward()
+    _grad_close(xg.grad, xr.grad, 5e-4)
+    for k, p in m.named_parameters():
+        _grad_close(p.grad, sd["rb." + k].grad, 5e-4)
+
+
 def test_normalizer_and_fusion_alone(monkeypatch):
     from mmsa_amd.model import ModalityFusion, MultifactorFeatureNormalizer
     torch.manual_seed(5)
@@ -116,6 +166,57 @@ def test_normalizer_and_fusion_alone(monkeypatch):
     torch.manual_seed(0)
     with torch.no_grad():
         _close(fu(an, tn), model_ref.fusion_features(sd, a, t, draws[0], draws[1]))
+
+
+def test_normalizer_and_fusion_alone_backward(monkeypatch):
+    """loss.backward() through the feature normaliser and the fusion layer on their own (multimodal_model.py:216-225,
+    263-285), with a dropped modality included: gradients against autograd through the oracle."""
+    from mmsa_amd.model import ModalityFusion, MultifactorFeatureNormalizer
+    torch.manual_seed(6)
+    fn = MultifactorFeatureNormalizer(256, 384).to(DEV)
+    fu = ModalityFusion(256, 384, hidden_dim=256, dropout_rate=0.0).to(DEV).train()
+    with torch.no_grad():
+        fn.audio_scale.fill_(1.3)
+        fn.text_scale.fill_(0.7)
+        for p in list(fn.audio_norm.parameters()) + list(fn.text_norm.parameters()):
+            p.normal_(0.5, 0.5)
+    a, t = torch.randn(6, 256), torch.randn(6, 384) * 2 + 1
+    R = torch.randn(6, 256)
+    for da, dt in ((False, False), (True, False), (False, True)):
+        monkeypatch.setattr(fu, "draw_modality_dropout", lambda d=(da, dt): d)
+        sd = model_ref.clone_state({**_sd(fn, "feature_normalizer"), **_sd(fu, "fusion_layer")}, requires_grad=True)
+        ar, tr = a.clone().requires_grad_(True), t.clone().requires_grad_(True)
+        (model_ref.fusion_features(sd, ar, tr, da, dt) * R).sum().backward()
+        for p in list(fn.parameters()) + list(fu.parameters()):
+            p.grad = None
+        ag, tg = a.to(DEV).requires_grad_(True), t.to(DEV).requires_grad_(True)
+        an, tn = fn(ag, tg)
+        (fu(an, tn) * R.to(DEV)).sum().backward()
+        _grad_close(ag.grad, ar.grad if ar.grad is not None else torch.zeros_like(a))    # dropped: no gradient
+        _grad_close(tg.grad, tr.grad if tr.grad is not None else torch.zeros_like(t))
+        for mod, prefix in ((fn, "feature_normalizer"), (fu, "fusion_layer")):
+            for k, p in mod.named_parameters():
+                want = sd[f"{prefix}.{k}"].grad
+                _grad_close(p.grad, want if want is not None else torch.zeros_like(p).cpu())
+
+
+def test_attention_alone_backward():
+    from mmsa_amd.model import Attention
+    torch.manual_seed(3)
+    m = Attention(64).to(DEV)
+    x = torch.randn(2, 5, 64)
+    R = torch.randn(2, 5, 64)
+    ref = {n: (getattr(m, n).weight.detach().cpu().clone().requires_grad_(True),
+               getattr(m, n).bias.detach().cpu().clone().requires_grad_(True)) for n in ("query", "key", "value")}
+    xr = x.clone().requires_grad_(True)
+    q, k, v = (torch.nn.functional.linear(xr, *ref[n]) for n in ("query", "key", "value"))
+    ((torch.softmax(q @ k.transpose(-2, -1) / 8.0, dim=-1) @ v) * R).sum().backward()
+    xg = x.to(DEV).requires_grad_(True)
+    (m(xg) * R.to(DEV)).sum().backward()
+    _grad_close(xg.grad, xr.grad)
+    for n in ("query", "key", "value"):
+        _grad_close(getattr(m, n).weight.grad, ref[n][0].grad)
+        _grad_close(getattr(m, n).bias.grad, ref[n][1].grad)
 
 
 def test_attention_alone():
