@@ -178,13 +178,23 @@ __global__ __launch_bounds__(1024) void logmel_norm_kernel(float* __restrict__ i
     const int* mk = specmask + 4 * blockIdx.x;
     mf0 = mk[0]; mfn = mk[1]; mt0 = mk[2]; mtn = mk[3];
   }
+  // (one workgroup's sixteen waves share four vector ALUs: this kernel's time is its instruction count, so the index
+  // division of the masks is only paid when there are masks)
   double s = 0.0;
-  for (int i = t; i < n_elem; i += 1024) {
-    float v = fmaxf(vals[i], floor_v);
-    const int row = i / n_frames, col = i - row * n_frames;
-    if ((unsigned)(row - mf0) < (unsigned)mfn || (unsigned)(col - mt0) < (unsigned)mtn) v = 0.f;
-    vals[i] = v;
-    s += (double)v;
+  if (mfn > 0 || mtn > 0) {   // uniform
+    for (int i = t; i < n_elem; i += 1024) {
+      float v = fmaxf(vals[i], floor_v);
+      const int row = i / n_frames, col = i - row * n_frames;
+      if ((unsigned)(row - mf0) < (unsigned)mfn || (unsigned)(col - mt0) < (unsigned)mtn) v = 0.f;
+      vals[i] = v;
+      s += (double)v;
+    }
+  } else {
+    for (int i = t; i < n_elem; i += 1024) {
+      const float v = fmaxf(vals[i], floor_v);
+      vals[i] = v;
+      s += (double)v;
+    }
   }
   s = block_sum_d(s, redd);
   const double mean = s / (double)n_elem;
