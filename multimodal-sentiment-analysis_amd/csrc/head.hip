@@ -178,7 +178,19 @@ __device__ __forceinline__ void matvec(const float* __restrict__ W, const float*
   else if (nit == 2) matvec_steps<2>(W, bias, x, out, K, N);
   else if (nit <= 4) matvec_steps<4>(W, bias, x, out, K, N);
   else if (nit <= 6) matvec_steps<6>(W, bias, x, out, K, N);
-  else matvec_steps<8>(W, bias, x, out, K, N);
+  else if (nit <= 8) matvec_steps<8>(W, bias, x, out, K, N);
+  else {
+    // rows longer than 512 columns (the attention layer over two projections wider than 256): eight steps at a time
+    for (int n0 = 0; n0 < N; n0 += 2 * (HT / LPR)) {
+      float a = 0.f, b = 0.f;
+      for (int it0 = 0; it0 < nit; it0 += 8) {
+        RowPieces<8> r;
+        rows_request_at(r, W, K, N, n0, it0);
+        rows_accumulate_at(r, x, a, b, K, it0);
+      }
+      rows_store(a, b, bias, out, N, n0);
+    }
+  }
 }
 
 // The same for a matrix already in LDS: the pieces are read as they are used (no registers set aside for a batch of
