@@ -28,6 +28,9 @@ def text_forward(m, input_ids: torch.Tensor, need_grad: bool, ws: Workspace):
         raise NotImplementedError("HIP text branch needs embedding_dim % 32 == 0 and num_filters % 64 == 0")
     if max(ksizes) > 7 or min(ksizes) < 2 or L < max(ksizes):
         raise NotImplementedError("HIP text branch supports filter sizes 2..7 and sequences at least that long")
+    if need_grad and (len(ksizes) > 4 or E % 64):
+        raise NotImplementedError("HIP text branch, backward: at most four filter widths and embedding_dim % 64 == 0 "
+                                  "(the forward alone, under torch.no_grad(), takes more widths and embedding_dim % 32)")
     st = SimpleNamespace(B=B, L=L, E=E, F=F, ksizes=ksizes, ids=ids)
     st.emb = ws.buf("text.emb", (B, L, E))
     # sticky flag: set by the gather / the backward scatter when a token id has no row in the table (a persistent
