@@ -108,6 +108,31 @@ def test_gradients_match_float64_oracle(modality, B):
     print(f"worst relative L2 gradient error vs float64 oracle: {worst:.2e}")
 
 
+@pytest.mark.parametrize("H,W,B", [(32, 50, 3), (96, 37, 2), (16, 130, 4), (64, 17, 5), (48, 101, 2)])
+def test_audio_model_at_other_map_sizes(H, W, B):
+    """Spectrograms of other heights (any multiple of 16) and widths, odd ones included, through the audio model in
+    training mode: logits and every gradient against the float64 oracle (bars as in the test below)."""
+    m = seeded_model("audio", vocab=SMALL_VOCAB).to(DEV).train()
+    sd = cpu_state(m)
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    audio = torch.randn(B, 1, H, W, generator=g)
+    label = torch.randint(0, 3, (B,), generator=g)
+    out = m(audio=audio.to(DEV), labels=label.to(DEV))
+    out["loss"].backward()
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    o64, g64, _ = model_ref.forward_backward(sd64, "audio", audio.double(), None, label)
+    _, g32, _ = model_ref.forward_backward(sd, "audio", audio, None, label)
+    close(out["logits"], o64["logits"])
+    for k, p in m.named_parameters():
+        if is_noise_grad("audio", k):
+            continue
+        r = g64[k]
+        n = torch.linalg.vector_norm(r) + 1e-30
+        err = float(torch.linalg.vector_norm(p.grad.detach().cpu().double() - r) / n)
+        err32 = float(torch.linalg.vector_norm(g32[k].double() - r) / n)
+        assert err < max(1e-3, 3 * err32), f"{k}: relative L2 error {err:.3e} (fp32 CPU oracle: {err32:.3e})"
+
+
 def test_gradients_for_a_spectrogram_of_another_length():
     """An 11 s utterance (64 x 460 frames) through the audio model: the first block's map (230 columns) is too wide for
     a double-buffered strip of the second-generation weight-gradient kernel, so the first generation serves it; the
