@@ -183,3 +183,32 @@ def test_front_end_output_is_standardised_per_utterance_at_batch_32():
     assert int(ok.sum()) >= B // 2                               # the statement is exact where nothing was clamped
     assert float(flat[ok].mean(1).abs().max()) < 1e-5 and float((flat[ok].std(1, unbiased=True) - 1).abs().max()) < 1e-5
     assert float(flat.abs().max()) <= 6.0
+
+
+def test_norms_over_more_chunks_than_the_norm_kernel_stages():
+    """Per-tensor norms and the global gradient norm over a flat buffer of 75 M floats in three tensors (4 600
+    16 K-element chunks: more than the one-workgroup norm kernel keeps in LDS, so it reads the chunk sums from memory),
+    and over a small one (staged), against torch's norms."""
+    from mmsa_amd import ops
+    from mmsa_amd.arena import ChunkTable
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    for sizes in ([70_000_000, 5_000_003, 17], [40_000, 3, 16_385]):
+        offsets, pos = [], 0
+        for n in sizes:
+            offsets.append(pos)
+            pos += (n + 255) // 256 * 256
+        table = ChunkTable(offsets, sizes, DEV)
+        assert (table.nchunks > 4096) == (sizes[0] > 10 ** 6)
+        g = torch.randn(pos, generator=gen, device=DEV)
+        tnorm = torch.zeros(len(sizes), device=DEV)
+        psum = torch.zeros(1, device=DEV)
+        ops.param_norms(g, table, tnorm, psum)
+        state = torch.zeros(8, device=DEV)
+        ops.grad_norm_finish(g, table, state, 0.9, 0.999, 1.0, True)
+        torch.cuda.synchronize()
+        want = torch.stack([g[o:o + n].double().norm() for o, n in zip(offsets, sizes)])
+        assert float((tnorm.double() - want).abs().max() / want.max()) < 1e-6
+        assert abs(float(psum) - float(want.sum())) < 1e-5 * float(want.sum())
+        total = float(want.square().sum().sqrt())
+        assert abs(float(state[4]) - total) < 1e-6 * total
+        assert float(state[0]) == 1.0 and abs(float(state[3]) - min(1.0, 1.0 / (total + 1e-6))) < 1e-6
