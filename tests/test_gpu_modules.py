@@ -100,7 +100,10 @@ def test_residual_block_alone(cin, cout, training):
 
 
 @pytest.mark.parametrize("cin,cout,training,hw", [(32, 64, True, (8, 12)), (64, 64, True, (7, 9)), (64, 128, False, (8, 12)),
-                                                   (128, 128, True, (6, 10)), (128, 256, True, (5, 8))])
+                                                   (128, 128, True, (6, 10)), (128, 256, True, (5, 8)),
+                                                   (96, 192, True, (6, 9)), (32, 256, True, (4, 6)),
+                                                   (160, 64, False, (5, 5)), (256, 256, True, (3, 4)),
+                                                   (192, 192, True, (2, 2)), (64, 64, True, (33, 70))])
 def test_residual_block_alone_backward(cin, cout, training, hw):
     """loss.backward() through a ResidualBlock used on its own (the reference's blocks are ordinary differentiable
     modules, multimodal_model.py:45-70): gradient of a random linear functional of the output with respect to the input
