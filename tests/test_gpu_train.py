@@ -52,6 +52,30 @@ def test_three_steps_match_oracle(modality):
         assert err < 0.08 * upd + 1e-6, f"{k}: update error {err:.3e} vs update size {upd:.3e}"
 
 
+@pytest.mark.parametrize("modality,B,L,W", [("both", 1, 128, 130), ("both", 5, 128, 130), ("both", 33, 128, 130),
+                                            ("both", 64, 128, 130), ("audio", 3, 128, 130), ("text", 2, 128, 130),
+                                            ("both", 4, 50, 91), ("both", 6, 17, 40), ("text", 3, 7, 130)])
+def test_first_step_at_other_batch_sizes(modality, B, L, W):
+    """A replayed step at batch sizes the kernels do not tile by (one utterance included), and at other token counts
+    and spectrogram widths: loss and clip norm against the oracle."""
+    from mmsa_amd.trainer import TrainStep
+    m = seeded_model(modality, vocab=SMALL_VOCAB).to(DEV).train()
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    if modality == "both":
+        m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+    ts = TrainStep(m, lr=1e-3, weight_decay=1e-4, max_norm=1.0, use_graph=True)
+    ref = train_ref.TrainState(sd0, modality)
+    b = batch_tensors(100, B, vocab=SMALL_VOCAB)
+    b["input_ids"] = b["input_ids"][:, :L].contiguous()
+    b["audio"] = b["audio"][..., :W].contiguous()
+    loss = ts.step(**_step_inputs(modality, {k: v.to(DEV) for k, v in b.items()}))
+    r = ref.step(b["audio"], b["input_ids"], b["label"], False, False)
+    assert abs(float(loss) - r["loss"]) < 1e-4, (float(loss), r["loss"])
+    assert abs(float(ts.grad_norm()) - r["grad_norm"]) < 2e-5 * max(1.0, r["grad_norm"])
+    ts.step(**_step_inputs(modality, {k: v.to(DEV) for k, v in b.items()}))      # the replay itself runs at this size
+    assert bool(torch.isfinite(m._arena.flat).all())
+
+
 def _record(name, payload):
     """Measured deviations go to gpurun_out/ (merged back from the GPU box; the copies judged are in profiles/)."""
     import json
