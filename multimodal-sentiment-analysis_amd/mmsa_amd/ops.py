@@ -209,18 +209,19 @@ def pack_weights(w: torch.Tensor, fwd: Optional[torch.Tensor], dgrad: Optional[t
 
 class PackPlan:
     """A device-resident table of (weight, forward pack, data-gradient pack) triples: one launch re-packs them all.
-    The table is rebuilt only when a pointer changes (weights and workspaces are persistent in training)."""
+    A table is built once per distinct set of pointers and kept for the plan's lifetime (weights and workspaces are
+    persistent in training): a captured launch sequence holds the table's address, so a table must neither move nor
+    change when a batch of another shape passes through the same plan."""
 
     def __init__(self):
-        self.key = None
-        self.table = None
-        self.n = 0
+        self.tables = {}
 
     def run(self, triples):
         import numpy as np
         key = tuple((w.data_ptr(), f.data_ptr() if f is not None else 0, d.data_ptr() if d is not None else 0)
                     for w, f, d in triples)
-        if key != self.key:
+        table = self.tables.get(key)
+        if table is None:
             rec = _lib.query("mmsa_conv_pack_desc_bytes")
             dt = np.dtype([("w", "<u8"), ("fwd", "<u8"), ("dgrad", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"),
                            ("ntaps", "<i4"), ("pad", "<i4")])
@@ -237,9 +238,8 @@ class PackPlan:
                     if x is not None and (x.numel() != w.numel() or _chk(x) == 0):
                         raise ValueError("packed buffer size mismatch")
                 arr[i] = (key[i][0], key[i][1], key[i][2], cout, cin, ntaps, 0)
-            self.table = torch.from_numpy(arr.view(np.uint8)).to(triples[0][0].device)
-            self.key, self.n = key, len(triples)
-        _lib.call("mmsa_conv_pack_weights_multi", self.table.data_ptr(), self.n, _stream())
+            table = self.tables[key] = torch.from_numpy(arr.view(np.uint8)).to(triples[0][0].device)
+        _lib.call("mmsa_conv_pack_weights_multi", table.data_ptr(), len(triples), _stream())
 
 
 def conv_tile_rows(B, H, W, Cout) -> int:
@@ -425,18 +425,17 @@ def conv_wgrad_slabs(X, dY, dY_sc, slabs, slabs_sc, B, H, W, Cin, Cout, taps=Non
 
 class ReducePlan:
     """A device-resident table of (slabs, dW, nslabs, ntaps, Cin, Cout) records: one launch sums the slabs of all of
-    them into the reference's [Cout][Cin][kh][kw] gradients.  The table is rebuilt only when an entry changes."""
+    them into the reference's [Cout][Cin][kh][kw] gradients.  A table is built once per distinct set of entries and kept
+    for the plan's lifetime (see PackPlan)."""
 
     def __init__(self):
-        self.key = None
-        self.table = None
-        self.n = 0
-        self.blocks = 0
+        self.tables = {}
 
     def run(self, entries):
         import numpy as np
         key = tuple((s.data_ptr(), d.data_ptr(), int(ns), int(nt), int(ci), int(co)) for s, d, ns, nt, ci, co in entries)
-        if key != self.key:
+        hit = self.tables.get(key)
+        if hit is None:
             dt = np.dtype([("slabs", "<u8"), ("dW", "<u8"), ("nslabs", "<i4"), ("ntaps", "<i4"), ("Cin", "<i4"),
                            ("Cout", "<i4"), ("block0", "<i4"), ("nblocks", "<i4")])
             if dt.itemsize != _lib.query("mmsa_conv_wgrad_reduce_desc_bytes"):
@@ -450,9 +449,8 @@ class ReducePlan:
                 nb = (nt * ci * co + 255) // 256
                 arr[i] = (key[i][0], key[i][1], ns, nt, ci, co, b0, nb)
                 b0 += nb
-            self.table = torch.from_numpy(arr.view(np.uint8)).to(entries[0][0].device)
-            self.key, self.n, self.blocks = key, len(entries), b0
-        _lib.call("mmsa_conv_wgrad_reduce_multi", self.table.data_ptr(), self.n, self.blocks, _stream())
+            hit = self.tables[key] = (torch.from_numpy(arr.view(np.uint8)).to(entries[0][0].device), b0)
+        _lib.call("mmsa_conv_wgrad_reduce_multi", hit[0].data_ptr(), len(entries), hit[1], _stream())
 
 
 # ---------------------------------------------------------------------------------------------- audio branch

@@ -302,13 +302,23 @@ class TrainStep:
         # (forward+backward, clip+AdamW) with the RCCL all-reduce issued eagerly between them, or three for
         # modality 'both' (forward + early backward | audio backward | clip+AdamW) with the first exchange
         # running underneath the second graph.
+        if self._graph is not None and any(t is not None and (self._static.get(k) is None
+                                                              or self._static[k].shape != t.shape)
+                                           for k, t in ins.items()):
+            # a batch of another shape than the captured one (the reference's training loader drops the last, short
+            # batch, multimodal_train.py:441; a caller's own loader may not): this step is launched kernel by kernel,
+            # the captured sequence stays as it is for the batches of the usual shape
+            if self.dist:
+                raise ValueError("graph mode on several ranks needs fixed input shapes (drop_last)")
+            self._copy_inputs(pending)
+            self._cur_ids = ins.get("input_ids")
+            self._body(ins["audio"], ins["input_ids"], ins["labels"], ins["wave"])
+            return self.loss
         for k, t in ins.items():
             if t is None:
                 continue
             s = self._static.get(k)
             if s is None or s.shape != t.shape:
-                if self._graph is not None:
-                    raise ValueError("graph mode needs fixed input shapes (the reference's loader uses drop_last)")
                 self._static[k] = t.clone()
             elif s.data_ptr() != t.data_ptr():
                 pending.append((s, t))

@@ -76,6 +76,34 @@ def test_first_step_at_other_batch_sizes(modality, B, L, W):
     assert bool(torch.isfinite(m._arena.flat).all())
 
 
+def test_a_short_batch_in_graph_mode_is_launched_eagerly():
+    """A batch of another size between replayed steps (a loader without drop_last): that step is launched kernel by
+    kernel and the captured sequence keeps serving the usual shape; a validation pass runs in between; the run equals
+    the all-eager run bit for bit.  (The descriptor tables a captured launch reads must survive the other shapes.)"""
+    from mmsa_amd.trainer import TrainStep
+    sizes = [8, 8, 8, 8, 5, 8, 3, 8]
+    res = []
+    for use_graph in (True, False):
+        m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+        m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+        ts = TrainStep(m, lr=1e-3, weight_decay=1e-4, max_norm=1.0, use_graph=use_graph)
+        losses = []
+        for s, B in enumerate(sizes):
+            b = batch_tensors(8 * s, B, vocab=SMALL_VOCAB)
+            losses.append(ts.step(**_step_inputs("both", {k: v.to(DEV) for k, v in b.items()})).clone())
+            if s == 3:      # a validation pass between training steps, at yet another batch size
+                m.eval()
+                v = batch_tensors(500, 11, vocab=SMALL_VOCAB)
+                with torch.no_grad():
+                    losses.append(m(**model_inputs("both", {k: t.to(DEV) for k, t in v.items()}),
+                                    labels=v["label"].to(DEV))["loss"].clone())
+                m.train()
+        assert (ts._graph is not None) == use_graph
+        res.append((torch.stack([x.reshape(()) for x in losses]), m._arena.flat.clone()))
+    assert torch.equal(res[0][0], res[1][0]), (res[0][0] - res[1][0]).abs()
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def _record(name, payload):
     """Measured deviations go to gpurun_out/ (merged back from the GPU box; the copies judged are in profiles/)."""
     import json
