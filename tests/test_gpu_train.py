@@ -104,6 +104,32 @@ def test_a_short_batch_in_graph_mode_is_launched_eagerly():
     assert torch.equal(res[0][1], res[1][1])
 
 
+def test_learning_rate_change_between_replayed_steps():
+    """A scheduler's learning-rate change (multimodal_train.py:314-320) in graph mode: the step is captured again with
+    the new rate; the run equals the eager run bit for bit, and the optimiser state round-trips through state_dict."""
+    from mmsa_amd.trainer import TrainStep
+    res = []
+    for use_graph in (True, False):
+        m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+        m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+        ts = TrainStep(m, lr=1e-3, weight_decay=1e-4, max_norm=1.0, use_graph=use_graph)
+        losses = []
+        for s in range(9):
+            if s == 4:
+                ts.set_lr(2.5e-4)
+            if s == 7:
+                ts.set_lr(2.5e-4)          # unchanged: no new capture
+                g_before = ts._graph
+            b = batch_tensors(8 * s, 8, vocab=SMALL_VOCAB)
+            losses.append(ts.step(**_step_inputs("both", {k: v.to(DEV) for k, v in b.items()})).clone())
+            if s == 7 and use_graph:
+                assert ts._graph is g_before
+        assert ts.state_dict()["param_groups"][0]["lr"] == 2.5e-4
+        res.append((torch.stack([x.reshape(()) for x in losses]), m._arena.flat.clone()))
+    assert torch.equal(res[0][0], res[1][0]), (res[0][0] - res[1][0]).abs()
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def _record(name, payload):
     """Measured deviations go to gpurun_out/ (merged back from the GPU box; the copies judged are in profiles/)."""
     import json
