@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void chunk_sumsq_kernel(const float* __restric
                                                           const long long* __restrict__ chunk_off,
                                                           const int* __restrict__ chunk_len,
                                                           const int* __restrict__ chunk_tensor,
-                                                          double* __restrict__ chunk_ss, const SparseRows sp) {
+                                                          double* __restrict__ chunk_ss, const SparseRows sp,
+                                                          int as_adamw) {
   __shared__ double red[16];
   const int c = blockIdx.x;
   const float* pa = a + chunk_off[c];
@@ -80,8 +81,24 @@ __global__ __launch_bounds__(256) void chunk_sumsq_kernel(const float* __restric
     if (threadIdx.x == 0) chunk_ss[c] = s;
     return;
   }
-  // 16-byte loads, four fp32 partial sums per thread (a few dozen terms each), combined in double
   const int n4 = n >> 2;
+  if (as_adamw) {
+    // the sums of squares of the parameters, term by term in the order in which adamw_kernel leaves them behind for
+    // the next step: a run that recomputes them (after a checkpoint is loaded) continues with the same bits as one
+    // that did not
+    const f32x4* q4 = reinterpret_cast<const f32x4*>(pa);
+    double ss = 0.0;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      const f32x4 v = q4[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ss += (double)v[k] * (double)v[k];
+    }
+    for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) ss += (double)pa[i] * (double)pa[i];
+    ss = block_sum_d(ss, red);
+    if (threadIdx.x == 0) chunk_ss[c] = ss;
+    return;
+  }
+  // 16-byte loads, four fp32 partial sums per thread (a few dozen terms each), combined in double
   const f32x4* a4 = reinterpret_cast<const f32x4*>(pa);
   const f32x4* b4 = reinterpret_cast<const f32x4*>(pb);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -351,7 +368,7 @@ MMSA_EXPORT int mmsa_param_norms(const float* p, const long long* chunk_off, con
   hipStream_t s = mmsa_stream(stream);
   if (!chunk_sums_ready)   // otherwise chunk_ss already holds the sums (written by the previous mmsa_adamw_step)
     hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, p, (const float*)nullptr,
-                       (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss, SparseRows{-1});
+                       (const float*)nullptr, 0.f, chunk_off, chunk_len, chunk_tensor, chunk_ss, SparseRows{-1}, 1);
   hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors, nchunks,
                      tnorm, sum_out, (float*)nullptr, StepScalars{});
   return mmsa_launch_status();
@@ -377,7 +394,7 @@ MMSA_EXPORT int mmsa_grad_norm(const float* g, const float* p, const float* tnor
   MMSA_REQUIRE((p == nullptr) == (tnorm == nullptr));
   hipStream_t s = mmsa_stream(stream);
   hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, g, p, tnorm, lambda, chunk_off, chunk_len,
-                     chunk_tensor, chunk_ss, SparseRows{-1});
+                     chunk_tensor, chunk_ss, SparseRows{-1}, 0);
   hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors, nchunks,
                      (float*)nullptr, (float*)nullptr, state + ST_GNORM, StepScalars{});
   return mmsa_launch_status();
@@ -407,7 +424,7 @@ MMSA_EXPORT int mmsa_grad_norm_finish(const float* g, const float* p, const floa
   }
   hipStream_t s = mmsa_stream(stream);
   hipLaunchKernelGGL(chunk_sumsq_kernel, dim3(nchunks), dim3(256), 0, s, g, p, tnorm, lambda, chunk_off, chunk_len,
-                     chunk_tensor, chunk_ss, sp);
+                     chunk_tensor, chunk_ss, sp, 0);
   hipLaunchKernelGGL(tensor_norms_kernel, dim3(1), dim3(1024), 0, s, chunk_ss, tensor_first_chunk, ntensors, nchunks,
                      (float*)nullptr, (float*)nullptr, state + ST_GNORM,
                      StepScalars{state, beta1, beta2, max_norm, do_clip});
