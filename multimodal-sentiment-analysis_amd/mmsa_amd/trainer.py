@@ -45,6 +45,12 @@ class TrainStep:
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: Optional[float] = 1.0, frontend=None,
                  use_graph: bool = False, process_group=None, bucket_mb: float = 64.0, distributed: bool = True):
         self.model = model
+        frozen = [k for k, p in model.named_parameters() if not p.requires_grad]
+        if frozen:
+            # torch.optim.AdamW leaves a parameter without a gradient alone (no decay, no moment update); the fused step
+            # updates the whole flat buffer.  Rather than train what the caller froze, refuse.
+            raise ValueError(f"TrainStep updates every parameter; {len(frozen)} are frozen (requires_grad=False), e.g. "
+                             f"{frozen[0]}: train a partly frozen model through loss.backward() and torch.optim.AdamW")
         self.arena = model._ensure_arena()
         dev = self.arena.device
         self.lr, self.wd, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm

@@ -130,6 +130,22 @@ def test_learning_rate_change_between_replayed_steps():
     assert torch.equal(res[0][1], res[1][1])
 
 
+def test_train_step_refuses_a_partly_frozen_model():
+    """torch.optim.AdamW skips parameters without a gradient; the fused step would decay and move them: it says so."""
+    from mmsa_amd.trainer import TrainStep
+    m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+    for p in m.text_model.parameters():
+        p.requires_grad_(False)
+    with pytest.raises(ValueError, match="frozen"):
+        TrainStep(m)
+    # the autograd path serves that case: frozen parameters receive no gradient
+    m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+    b = batch_tensors(0, 4, vocab=SMALL_VOCAB, device=DEV)
+    m(**model_inputs("both", b), labels=b["label"])["loss"].backward()
+    assert all(p.grad is None for p in m.text_model.parameters())
+    assert all(p.grad is not None for p in m.audio_model.parameters())
+
+
 def _record(name, payload):
     """Measured deviations go to gpurun_out/ (merged back from the GPU box; the copies judged are in profiles/)."""
     import json
