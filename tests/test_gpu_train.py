@@ -146,6 +146,38 @@ def test_train_step_refuses_a_partly_frozen_model():
     assert all(p.grad is not None for p in m.audio_model.parameters())
 
 
+def test_reference_amp_loop_on_the_drop_in_model():
+    """The reference's --use_amp branch (multimodal_train.py:178-189: autocast around the forward, GradScaler around
+    backward / unscale_ / clip / step) on the drop-in model: the kernels compute in float32 whatever the autocast state
+    and the loss scale is a power of two, so the losses equal those of the plain loop."""
+    res = []
+    for use_amp in (False, True):
+        m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+        m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-4)
+        scaler = torch.amp.GradScaler("cuda") if use_amp else None
+        losses = []
+        for s in range(3):
+            b = batch_tensors(8 * s, 8, vocab=SMALL_VOCAB, device=DEV)
+            opt.zero_grad()
+            if use_amp:
+                with torch.autocast("cuda"):
+                    loss = m(**model_inputs("both", b), labels=b["label"])["loss"]
+                scaler.scale(loss).backward()
+                scaler.unscale_(opt)
+                torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1.0)
+                scaler.step(opt)
+                scaler.update()
+            else:
+                loss = m(**model_inputs("both", b), labels=b["label"])["loss"]
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1.0)
+                opt.step()
+            losses.append(float(loss.detach()))
+        res.append(losses)
+    assert res[0] == res[1]
+
+
 def _record(name, payload):
     """Measured deviations go to gpurun_out/ (merged back from the GPU box; the copies judged are in profiles/)."""
     import json
