@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5))) void l
 #pragma unroll
     for (int f = 0; f < FPB; ++f) {
       float a = acc[f];
-      a += __shfl_xor(a, 1, 64);
-      a += __shfl_xor(a, 2, 64);
+      a += dpp_mov<DPP_XOR1>(a);     // the four lanes of a filter (every lane is enabled here)
+      a += dpp_mov<DPP_XOR2>(a);
       if (q == 0) dbv[m][f] = 10.0f * log10f(fmaxf(a, 1e-10f));
     }
   }
