@@ -57,7 +57,7 @@ def test_forward_backward_match_oracle():
     np.testing.assert_allclose(out["logits"].detach().cpu().numpy(), ref["logits"].detach().numpy(), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(out["attention_weights"].detach().cpu().numpy(), ref["attention_weights"].detach().numpy(),
                                rtol=1e-4, atol=1e-6)
-    assert abs(float(out["loss"].detach()) - float(ref["loss"])) < 1e-5
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 1e-5
     assert torch.equal(out["logits"].argmax(1).cpu(), ref["logits"].argmax(1))
     for k, p in m.named_parameters():
         g, r = p.grad.detach().cpu().double(), w[k].grad
@@ -123,3 +123,40 @@ def test_eval_and_layer_alone():
     m.train()                      # dropout active: runs, differs from eval, stays finite
     o2 = m(t.to(DEV), a.to(DEV))
     assert torch.isfinite(o2["logits"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("td,ad,fd,nc,B", [(128, 768, 512, 3, 1), (128, 768, 512, 3, 33), (64, 256, 128, 2, 8),
+                                           (100, 300, 96, 5, 7), (768, 768, 1024, 3, 4), (32, 40, 64, 7, 130)])
+def test_other_widths_and_batch_sizes_match_oracle(td, ad, fd, nc, B):
+    """Feature, fusion and class widths other than the reference's, including odd ones, and the gradients that flow
+    back into the pooled features (the encoders upstream of this head receive them)."""
+    from mmsa_amd.fusion_head import HybridFusionHead
+    torch.manual_seed(7)
+    m = HybridFusionHead(td, ad, fd, nc, 0.0).to(DEV).train()
+    with torch.no_grad():                      # the reference initialises biases to zero: make them matter here
+        for k, p in m.named_parameters():
+            if k.endswith(".bias"):
+                p.normal_(0, 0.1)
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(B)
+    t, a, y = torch.randn(B, td, generator=g), torch.randn(B, ad, generator=g), torch.randint(0, nc, (B,), generator=g)
+    tg, ag = t.to(DEV).requires_grad_(True), a.to(DEV).requires_grad_(True)
+    out = m(tg, ag, labels=y.to(DEV))
+    out["loss"].backward()
+    w = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    tr, ar = t.double().requires_grad_(True), a.double().requires_grad_(True)
+    ref = fusion_head_ref.forward(w, tr, ar, y)
+    ref["loss"].backward()
+    np.testing.assert_allclose(out["logits"].detach().cpu().numpy(), ref["logits"].detach().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(out["attention_weights"].detach().cpu().numpy(), ref["attention_weights"].detach().numpy(),
+                               rtol=2e-4, atol=1e-6)
+    assert abs(float(out["loss"].detach()) - float(ref["loss"])) < 2e-5
+    pairs = [(k, p.grad, w[k].grad) for k, p in m.named_parameters()] + [("text", tg.grad, tr.grad), ("audio", ag.grad, ar.grad)]
+    for k, gg, r in pairs:
+        gg = gg.detach().cpu().double()
+        if k == SHIFT_BIAS:
+            assert float(gg.abs().max()) < 1e-6
+            continue
+        err = float(torch.linalg.vector_norm(gg - r) / (torch.linalg.vector_norm(r) + 1e-30))
+        assert err < 2e-4, f"{k}: relative L2 error {err:.2e}"
