@@ -791,12 +791,12 @@ template <int BM, int BN, int WM_, int WN_, bool STATS, bool ACCUM, int NB, bool
 int launch_igemm_ring(const float* X, const float* Wp, float* Y, float* stats, const ConvGeom& g, int tiles, dim3 grid,
                       const ConvMulti& multi, hipStream_t s) {
   constexpr size_t shmem = NB * (size_t)(BM + BN) * KC * sizeof(float);
-  static bool attr_set = false;   // raising the dynamic-LDS limit is sticky per kernel; benign if raced
-  if (shmem > 48 * 1024 && !attr_set) {
+  static PerDeviceOnce attr_set;   // raising the dynamic-LDS limit is sticky per kernel and device
+  if (shmem > 48 * 1024 && attr_set.pending()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM, NB, BNRELU>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
       return MMSA_ERR_LAUNCH;
-    attr_set = true;
+    attr_set.done();
   }
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM_, WN_, STATS, ACCUM, NB, BNRELU>), grid, dim3(512), shmem, s, X, Wp,
                      Y, stats, g, tiles, multi);

@@ -530,12 +530,12 @@ static int rows3_mode() {
 template <int BM, int BN, int WM_, int WN_, int STATS, bool ACCUM, bool BNRELU>
 int launch_igemm3_inst(const float* X, const ConvGeom& g, const Conv3Args& a, hipStream_t s) {
   constexpr size_t shmem = ((BM == 64 ? 4 : 3) * (size_t)(BM + 8) + 5 * (size_t)BN) * KC * sizeof(float);
-  static bool attr_set = false;
-  if (shmem > 48 * 1024 && !attr_set) {
+  static PerDeviceOnce attr_set;
+  if (shmem > 48 * 1024 && attr_set.pending()) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm3_kernel<BM, BN, WM_, WN_, STATS, ACCUM, BNRELU>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) != hipSuccess)
       return MMSA_ERR_LAUNCH;
-    attr_set = true;
+    attr_set.done();
   }
   const int tiles = mmsa_cdiv((long)g.H * g.W, BM);
   dim3 grid(g.B * tiles, g.Cout / BN, a.n);

@@ -996,12 +996,12 @@ bool staged_ok(const HeadDims& d) {
 }
 
 template <typename K>
-int launch_staged(K kernel, size_t lds, bool& attr_set, int B, hipStream_t s, const HeadPtrs& hp, const HeadDims& hd) {
-  if (!attr_set) {   // raising the dynamic-LDS limit is sticky per kernel; benign if raced
+int launch_staged(K kernel, size_t lds, PerDeviceOnce& attr_set, int B, hipStream_t s, const HeadPtrs& hp, const HeadDims& hd) {
+  if (attr_set.pending()) {   // raising the dynamic-LDS limit is sticky per kernel and device
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return MMSA_ERR_LAUNCH;
-    attr_set = true;
+    attr_set.done();
   }
   hipLaunchKernelGGL(kernel, dim3(B), dim3(HT), lds, s, hp, hd);
   return mmsa_launch_status();
@@ -1108,7 +1108,7 @@ MMSA_EXPORT int mmsa_head_both_fwd(const void* const* ptrs_host, int nptrs, int 
   const int rc = fill(hp, hd, ptrs_host, nptrs, S_AFEAT, S_LOGITS, B, A, T, Hd, N0, N1, C, drop_p, seed, grad_scale);
   if (rc != MMSA_OK) return rc;
   if (staged_ok(hd)) {
-    static bool attr_set = false;
+    static PerDeviceOnce attr_set;
     return launch_staged(head_both_fwd_staged_kernel, FWD_STAGED_LDS, attr_set, B, mmsa_stream(stream), hp, hd);
   }
   hipLaunchKernelGGL(head_both_fwd_kernel, dim3(B), dim3(HT), 0, mmsa_stream(stream), hp, hd);
@@ -1124,7 +1124,7 @@ MMSA_EXPORT int mmsa_head_both_bwd(const void* const* ptrs_host, int nptrs, int 
   const int rc = fill(hp, hd, ptrs_host, nptrs, S_AFEAT, S_D_TFEAT, B, A, T, Hd, N0, N1, C, drop_p, seed);
   if (rc != MMSA_OK) return rc;
   if (staged_ok(hd)) {
-    static bool attr_set = false;
+    static PerDeviceOnce attr_set;
     return launch_staged(head_both_bwd_staged_kernel, BWD_STAGED_LDS, attr_set, B, mmsa_stream(stream), hp, hd);
   }
   hipLaunchKernelGGL(head_both_bwd_kernel, dim3(B), dim3(HT), 0, mmsa_stream(stream), hp, hd);

@@ -26,6 +26,25 @@ static inline hipStream_t mmsa_stream(void* s) { return reinterpret_cast<hipStre
 
 static inline int mmsa_cdiv(long a, long b) { return static_cast<int>((a + b - 1) / b); }
 
+// A call that has to be made once per device (raising a kernel's dynamic-LDS limit belongs to the device that is
+// current when it is made): pending() is true until done() has run with that device current.  A process that drives
+// several GPUs gets the call on each of them.  Races are benign, the guarded calls are idempotent.
+struct PerDeviceOnce {
+  unsigned long long seen = 0;
+  static int current() {
+    int d = 0;
+    return hipGetDevice(&d) == hipSuccess && d >= 0 && d < 64 ? d : -1;
+  }
+  bool pending() const {
+    const int d = current();
+    return d < 0 || !((seen >> d) & 1ull);
+  }
+  void done() {
+    const int d = current();
+    if (d >= 0) seen |= 1ull << d;
+  }
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

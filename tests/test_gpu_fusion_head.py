@@ -68,7 +68,7 @@ def test_forward_backward_match_oracle():
         assert err < 1e-4, f"{k}: relative L2 error {err:.2e}"
     # float -1/0/1 labels are shifted by one, like the reference
     out2 = m(t.to(DEV), a.to(DEV), labels=(y.float() - 1).to(DEV))
-    assert abs(float(out2["loss"].detach()) - float(ref["loss"])) < 1e-5
+    assert abs(float(out2["loss"].detach()) - float(ref["loss"].detach())) < 1e-5
 
 
 @pytest.mark.gpu
