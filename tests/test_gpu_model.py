@@ -311,3 +311,35 @@ def test_eval_forward_odd_batch_sizes_and_padding_rows(B):
     close(got["logits"], ref["logits"].numpy())
     assert torch.equal(got["logits"].argmax(1).cpu(), ref["logits"].argmax(1))
     assert abs(float(got["loss"]) - float(ref["loss"])) < 1e-4
+
+
+@pytest.mark.parametrize("modality", ["text", "audio", "both"])
+def test_backward_in_eval_mode_matches_oracle(modality):
+    """Gradients taken with the model in eval mode (saliency maps, fine-tuning with frozen BatchNorm statistics): every
+    BatchNorm is then a fixed affine map built from its running statistics, which the backward pass must use too, and
+    the statistics themselves stay as they are.  The running statistics come from twenty training-mode forward passes:
+    with statistics far from the data's every channel is a constant plus a ripple, the pooling windows are full of
+    near-ties and the comparison measures which way each implementation's rounding tips them."""
+    m = seeded_model(modality, vocab=SMALL_VOCAB).to(DEV).train()
+    with torch.no_grad():
+        for i in range(20):
+            m(**model_inputs(modality, batch_tensors(100 + 8 * i, 8, vocab=SMALL_VOCAB, device=DEV)))
+    m.eval()
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    b = batch_tensors(11, 6, vocab=SMALL_VOCAB)
+    bd = {k: v.to(DEV) for k, v in b.items()}
+    out = m(**model_inputs(modality, bd), labels=bd["label"])
+    out["loss"].backward()
+    w = model_ref.clone_state(sd, requires_grad=True)
+    ref = model_ref.forward(w, modality, b["audio"] if modality != "text" else None,
+                            b["input_ids"] if modality != "audio" else None, b["label"], training=False)
+    ref["loss"].backward()
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 1e-5
+    for k, p in m.named_parameters():
+        r = w[k].grad if w[k].grad is not None else torch.zeros_like(w[k])
+        assert p.grad is not None, k
+        err = float(torch.linalg.vector_norm(p.grad.cpu() - r))
+        assert err <= 1e-4 * float(torch.linalg.vector_norm(r)) + 1e-7, f"{k}: {err:.2e}"
+    for k, v in m.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(v.cpu(), sd[k]), k
