@@ -309,6 +309,14 @@ def _needs_grad(module: nn.Module) -> bool:
     return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
 
 
+def _refuse_spectrogram_grad(x) -> None:
+    """The stem's backward forms parameter gradients only (training never asks for more): a gradient with respect to
+    the spectrogram would silently come back as None, so asking for one is refused."""
+    if x is not None and torch.is_grad_enabled() and x.requires_grad:
+        raise NotImplementedError("gradients with respect to the input spectrogram are not computed by the HIP "
+                                  "backward pass; detach the input")
+
+
 class _BranchFn(torch.autograd.Function):
     """Autograd bridge for a single branch used on its own (AudioModel(x) / TextModel(ids))."""
 
@@ -367,6 +375,7 @@ class AudioModel(nn.Module):
 
     def forward(self, x):
         dev = _require_gpu(self, "AudioModel")
+        _refuse_spectrogram_grad(x)
         x = x.to(device=dev, dtype=torch.float32)
         if _needs_grad(self):
             return _BranchFn.apply(self, x, *self.parameters())
@@ -793,6 +802,7 @@ class MultimodalSentimentModel(nn.Module):
         arena = self._ensure_arena()
         dev = arena.device
         if audio is not None and self.modality != "text":
+            _refuse_spectrogram_grad(audio)
             audio = audio.to(device=dev, dtype=torch.float32)
         if input_ids is not None and self.modality != "audio":
             input_ids = input_ids.to(dev)

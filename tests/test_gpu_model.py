@@ -343,3 +343,29 @@ def test_backward_in_eval_mode_matches_oracle(modality):
     for k, v in m.state_dict().items():
         if "running" in k or "num_batches" in k:
             assert torch.equal(v.cpu(), sd[k]), k
+
+
+def test_eager_backward_with_a_frozen_branch_and_refusal_of_spectrogram_gradients():
+    """Freezing the audio branch (requires_grad False) and calling loss.backward(): the frozen parameters get no
+    gradient, the others get exactly what the unfrozen model gives them.  A spectrogram that asks for a gradient is
+    refused instead of being handed None."""
+    b = batch_tensors(21, 5, vocab=SMALL_VOCAB, device=DEV)
+    full = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+    full.fusion_layer.draw_modality_dropout = lambda: (False, False)
+    full(**model_inputs("both", b), labels=b["label"])["loss"].backward()
+    m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+    m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+    for p in m.audio_model.parameters():
+        p.requires_grad_(False)
+    m(**model_inputs("both", b), labels=b["label"])["loss"].backward()
+    for (k, p), q in zip(m.named_parameters(), full.parameters()):
+        if k.startswith("audio_model."):
+            assert p.grad is None, k
+        else:
+            assert torch.equal(p.grad, q.grad), k
+    with pytest.raises(NotImplementedError, match="spectrogram"):
+        m(audio=b["audio"].clone().requires_grad_(True), input_ids=b["input_ids"])
+    with pytest.raises(NotImplementedError, match="spectrogram"):
+        m.audio_model(b["audio"].clone().requires_grad_(True))
+    with torch.no_grad():                                  # nothing is being differentiated: no refusal
+        m(audio=b["audio"].clone().requires_grad_(True), input_ids=b["input_ids"])
