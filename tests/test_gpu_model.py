@@ -369,3 +369,36 @@ def test_eager_backward_with_a_frozen_branch_and_refusal_of_spectrogram_gradient
         m.audio_model(b["audio"].clone().requires_grad_(True))
     with torch.no_grad():                                  # nothing is being differentiated: no refusal
         m(audio=b["audio"].clone().requires_grad_(True), input_ids=b["input_ids"])
+
+
+@pytest.mark.parametrize("how", ["deepcopy", "torch.save", "cpu round trip"])
+def test_copies_of_a_model_that_has_already_run(how):
+    """copy.deepcopy (snapshots of the best model, moving averages), torch.save of the whole module and a trip through
+    host memory, all taken after the model has run on the GPU (so it carries its parameter arena and workspaces): the
+    copy gives the same logits, is independent of the original and trains."""
+    import copy
+    import io
+    m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+    b = batch_tensors(3, 4, vocab=SMALL_VOCAB, device=DEV)
+    m(**model_inputs("both", b), labels=b["label"])["loss"].backward()
+    m.eval()
+    with torch.no_grad():
+        ref = m(**model_inputs("both", b))["logits"].clone()
+    if how == "deepcopy":
+        c = copy.deepcopy(m)
+    elif how == "torch.save":
+        buf = io.BytesIO()
+        torch.save(m, buf)
+        buf.seek(0)
+        c = torch.load(buf, weights_only=False)           # a file this test wrote itself
+    else:
+        c = copy.deepcopy(m).cpu().to(DEV)
+    with torch.no_grad():
+        assert torch.equal(c(**model_inputs("both", b))["logits"], ref)
+        for p in c.parameters():
+            p.add_(0.01)
+        assert torch.equal(m(**model_inputs("both", b))["logits"], ref)
+        assert not torch.equal(c(**model_inputs("both", b))["logits"], ref)
+    c.train()
+    c(**model_inputs("both", b), labels=b["label"])["loss"].backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in c.parameters())
