@@ -43,8 +43,16 @@ def dist_backend_is_stream_ordered(group) -> bool:
 class TrainStep:
     def __init__(self, model: MultimodalSentimentModel, lr: float = 1e-3, weight_decay: float = 1e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: Optional[float] = 1.0, frontend=None,
-                 use_graph: bool = False, process_group=None, bucket_mb: float = 64.0, distributed: bool = True):
+                 use_graph: bool = False, process_group=None, bucket_mb: float = 64.0, distributed: bool = True,
+                 lr_from=None):
+        """``lr_from``: a ``torch.optim`` optimiser whose first group's ``lr`` this step follows (read before every
+        step).  The reference's schedulers (``ReduceLROnPlateau``, the cosine warm-up; multimodal_train.py:487-504,
+        314-320) only accept a stock optimiser: keep the reference's ``optim.AdamW(model.parameters(), lr=...)`` as
+        the object they drive -- its ``step()`` is never called -- and hand it over here."""
         self.model = model
+        self.lr_from = lr_from
+        if lr_from is not None:
+            lr = float(lr_from.param_groups[0]["lr"])
         frozen = [k for k, p in model.named_parameters() if not p.requires_grad]
         if frozen:
             # torch.optim.AdamW leaves a parameter without a gradient alone (no decay, no moment update); the fused step
@@ -260,6 +268,8 @@ class TrainStep:
             raise ValueError("pass frontend=LogMelFrontEnd(...) to train from waveforms")
         if not model.training:
             raise RuntimeError("TrainStep.step() needs model.train()")
+        if self.lr_from is not None:
+            self.set_lr(self.lr_from.param_groups[0]["lr"])
         # parameter sums left by the previous step stay valid only if nobody else wrote the parameters since
         # (load_state_dict, a user optimiser, ...): torch's version counters tell
         pv = sum(p._version for p in self.arena.params)

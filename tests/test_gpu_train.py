@@ -130,6 +130,42 @@ def test_learning_rate_change_between_replayed_steps():
     assert torch.equal(res[0][1], res[1][1])
 
 
+def test_reference_scheduler_drives_the_step_through_a_carrier_optimizer():
+    """The reference builds ReduceLROnPlateau(optimizer, mode='min', factor=0.5, patience=2) on its AdamW and steps it
+    once per epoch (multimodal_train.py:499-504, 317-318).  Schedulers accept stock optimisers only, so the drop-in
+    keeps that AdamW as the object the scheduler drives and TrainStep(lr_from=...) follows its rate: same bits as
+    setting the rates by hand, in graph mode."""
+    from torch.optim.lr_scheduler import ReduceLROnPlateau
+    from mmsa_amd.trainer import TrainStep
+    res = []
+    for follow in (True, False):
+        m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+        m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+        if follow:
+            carrier = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-4)
+            sched = ReduceLROnPlateau(carrier, mode="min", factor=0.5, patience=0)
+            ts = TrainStep(m, weight_decay=1e-4, max_norm=1.0, use_graph=True, lr_from=carrier)
+        else:
+            ts = TrainStep(m, lr=1e-3, weight_decay=1e-4, max_norm=1.0, use_graph=True)
+        losses, rates = [], []
+        for s in range(9):
+            if s in (3, 6):                                  # an "epoch" ends; validation loss got worse each time
+                if follow:
+                    sched.step(1.0 + s)
+                else:
+                    ts.set_lr(1e-3 if s == 3 else 5e-4)      # patience 0: the first bad epoch after the best halves
+            b = batch_tensors(8 * s, 8, vocab=SMALL_VOCAB)
+            losses.append(ts.step(**_step_inputs("both", {k: v.to(DEV) for k, v in b.items()})).clone())
+            rates.append(ts.lr)
+        if follow:
+            assert rates == [1e-3] * 6 + [5e-4] * 3, rates
+            assert ts.state_dict()["param_groups"][0]["lr"] == carrier.param_groups[0]["lr"] == 5e-4
+            assert not carrier.state_dict()["state"]          # the carrier never stepped
+        res.append((torch.stack([x.reshape(()) for x in losses]), m._arena.flat.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def test_train_step_refuses_a_partly_frozen_model():
     """torch.optim.AdamW skips parameters without a gradient; the fused step would decay and move them: it says so."""
     from mmsa_amd.trainer import TrainStep
