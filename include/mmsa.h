@@ -386,8 +386,11 @@ MMSA_API int mmsa_dropout(const float* x, float* y, long n, float drop_p, unsign
 MMSA_API int mmsa_param_norms(const float* p, const long long* chunk_off, const int* chunk_len, const int* chunk_tensor,
                               int nchunks, const int* tensor_first_chunk, int ntensors, double* chunk_ss, float* tnorm,
                               float* sum_out, int chunk_sums_ready, void* stream);
-MMSA_API int mmsa_l2_grad_add(float* g, const float* p, const float* tnorm, float lambda, const long long* chunk_off,
-                              const int* chunk_len, const int* chunk_tensor, int nchunks, void* stream);
+/* g += (lambda * *scale) * p / ||p|| per tensor; scale: one float in device memory, or NULL for 1 (the gradient
+   arriving at the loss, which autograd hands over as a device scalar: no host read of it is needed) */
+MMSA_API int mmsa_l2_grad_add(float* g, const float* p, const float* tnorm, float lambda, const float* scale,
+                              const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,
+                              void* stream);
 /* state[4] = global norm of g (+ lambda * p / ||p|| per tensor when p and tnorm are given) */
 MMSA_API int mmsa_grad_norm(const float* g, const float* p, const float* tnorm, float lambda,
                             const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,

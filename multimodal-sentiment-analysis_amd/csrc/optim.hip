@@ -230,12 +230,13 @@ __global__ __launch_bounds__(1024) void tensor_norms_kernel(const double* __rest
 }
 
 __global__ void l2_grad_add_kernel(float* __restrict__ g, const float* __restrict__ p, const float* __restrict__ tnorm,
-                                   float lambda, const long long* __restrict__ chunk_off,
-                                   const int* __restrict__ chunk_len, const int* __restrict__ chunk_tensor) {
+                                   float lambda, const float* __restrict__ scale,
+                                   const long long* __restrict__ chunk_off, const int* __restrict__ chunk_len,
+                                   const int* __restrict__ chunk_tensor) {
   const int c = blockIdx.x;
   const float nm = tnorm[chunk_tensor[c]];
   if (!(nm > 0.f)) return;
-  const float coef = lambda / nm;
+  const float coef = (scale ? lambda * scale[0] : lambda) / nm;
   float* pg = g + chunk_off[c];
   const float* pp = p + chunk_off[c];
   const int n = chunk_len[c];
@@ -375,11 +376,13 @@ MMSA_EXPORT int mmsa_param_norms(const float* p, const long long* chunk_off, con
 }
 
 // g += lambda * p / ||p|| per tensor (tensors with zero norm are left alone, as torch.norm's gradient is 0 there)
-MMSA_EXPORT int mmsa_l2_grad_add(float* g, const float* p, const float* tnorm, float lambda, const long long* chunk_off,
-                                 const int* chunk_len, const int* chunk_tensor, int nchunks, void* stream) {
+// (scale: optional device scalar that multiplies lambda)
+MMSA_EXPORT int mmsa_l2_grad_add(float* g, const float* p, const float* tnorm, float lambda, const float* scale,
+                                 const long long* chunk_off, const int* chunk_len, const int* chunk_tensor, int nchunks,
+                                 void* stream) {
   MMSA_REQUIRE(g && p && tnorm && chunk_off && chunk_len && chunk_tensor && nchunks > 0);
-  hipLaunchKernelGGL(l2_grad_add_kernel, dim3(nchunks), dim3(256), 0, mmsa_stream(stream), g, p, tnorm, lambda, chunk_off,
-                     chunk_len, chunk_tensor);
+  hipLaunchKernelGGL(l2_grad_add_kernel, dim3(nchunks), dim3(256), 0, mmsa_stream(stream), g, p, tnorm, lambda, scale,
+                     chunk_off, chunk_len, chunk_tensor);
   return mmsa_launch_status();
 }
 

@@ -16,6 +16,7 @@ Training support comes in two forms:
 from __future__ import annotations
 
 import os
+import weakref
 
 from typing import List, Optional
 
@@ -551,23 +552,40 @@ class _FusionFn(torch.autograd.Function):
         return (None, d_a, d_t, None, None, None, None) + tuple(grads.of(q, zero=True) for q in m.parameters())
 
 
+# per model: one int of pinned host memory and an event, through which the eager forward learns whether the embedding
+# gather met a token id outside the table (kept outside the module: neither copies nor pickles well)
+_ID_PROBES = weakref.WeakKeyDictionary()
+
+
+def _ids_probe(model, dev):
+    probe = _ID_PROBES.get(model)
+    if probe is None or probe[2] != dev:
+        probe = (torch.zeros(1, dtype=torch.int32).pin_memory(), torch.cuda.Event(), dev)
+        _ID_PROBES[model] = probe
+    return probe
+
+
 class _ModelFn(torch.autograd.Function):
     """One autograd node for the whole model: forward and backward are HIP launch sequences."""
 
     @staticmethod
     def forward(ctx, model, audio, input_ids, labels, drops, *params):
-        run = model._run(audio, input_ids, labels, drops, need_grad=True, ws=Workspace(params[0].device, False))
+        ws = Workspace(params[0].device, False)
+        if model.text_model is not None:
+            ws.objs["text.err_probe"] = _ids_probe(model, params[0].device)
+        run = model._run(audio, input_ids, labels, drops, need_grad=True, ws=ws)
         if run.text is not None:
-            text_engine.check_ids(run.text.err)
-        ctx.model, ctx.run = model, run
+            # raises IndexError like the reference's nn.Embedding, having waited for the gather, not for the pass
+            text_engine.check_ids_probe(ws.objs["text.err_probe"])
+        ctx.model, ctx.run, ctx.arena = model, run, model._arena
         ctx.set_materialize_grads(False)
         loss = run.loss.view(()).clone() if run.loss is not None else None
         return run.head.logits.clone(), run.head.probs.clone(), loss
 
     @staticmethod
     def backward(ctx, g_logits, g_probs, g_loss):
-        model, run = ctx.model, ctx.run
-        plist = list(model.parameters())
+        model, run, arena = ctx.model, ctx.run, ctx.arena
+        plist = arena.params
         d = None
         if g_loss is not None and run.head.dlogits is not None:
             d = run.head.dlogits * g_loss
@@ -580,13 +598,16 @@ class _ModelFn(torch.autograd.Function):
         none = (None,) * 5
         if d is None:
             return none + tuple(None for _ in plist)
-        gflat = torch.empty_like(model._arena.flat)
-        views = model._arena.views_of(gflat)
+        gflat = torch.empty_like(arena.flat)
+        views = arena.views_of(gflat)
         grads = Grads({id(p): v for p, v in zip(plist, views)})
         model._backward(run, d.contiguous(), grads)
         if run.l2 and g_loss is not None:
             # d/dp of 0.001 * ||p||: lambda * p / ||p|| per tensor, scaled by the incoming loss gradient
-            ops.l2_grad_add(gflat, model._arena.flat, model._arena.tnorm, L2_LAMBDA * float(g_loss), model._arena.table)
+            # (the incoming gradient stays on the device: reading it here would make the host wait for the whole
+            # backward pass it has just enqueued)
+            ops.l2_grad_add(gflat, arena.flat, arena.tnorm, L2_LAMBDA, arena.table,
+                            scale=g_loss.detach().to(torch.float32).reshape(1))
         missing = [p for p in plist if id(p) not in run.touched]
         for p in missing:
             grads.of(p).zero_()
@@ -648,13 +669,18 @@ class MultimodalSentimentModel(nn.Module):
 
     # ------------------------------------------------------------------ plumbing
     def _ensure_arena(self) -> ParamArena:
+        """The flat parameter storage, rebuilt when the parameters no longer live in it: after ``.to()`` /
+        ``.float()`` (new storage) or after a layer was exchanged (other Parameter objects).  One walk over the module
+        tree per call; callers take the parameter list from the arena instead of walking again."""
         dev = _require_gpu(self, "MultimodalSentimentModel")
         a = self.__dict__.get("_arena")
-        if a is None or a.device != dev or not a.owns():
-            for p in self.parameters():
+        cur = list(self.parameters())
+        if (a is None or a.device != dev or len(cur) != len(a.params)
+                or any(x is not y for x, y in zip(cur, a.params)) or not a.owns()):
+            for p in cur:
                 if p.dtype != torch.float32:
                     raise TypeError("the HIP kernels compute in float32; convert the model with .float()")
-            a = ParamArena(list(self.parameters()), dev)
+            a = ParamArena(cur, dev)
             self.__dict__["_arena"] = a
             self.__dict__["_ws_infer"] = Workspace(dev)
             self.__dict__["_consts"] = {1: torch.ones(1, device=dev), 0: torch.zeros(1, device=dev)}
@@ -744,7 +770,7 @@ class MultimodalSentimentModel(nn.Module):
             else:
                 total_loss()
         if need_grad:
-            run.touched = {id(p) for p in self.parameters()}
+            run.touched = {id(p) for p in arena.params}
         return run
 
     def _backward(self, run, dlogits, grads: Grads, ws: Optional[Workspace] = None, phase: str = "all"):
@@ -811,8 +837,8 @@ class MultimodalSentimentModel(nn.Module):
         drops = (False, False)
         if self.modality == "both":
             drops = self.fusion_layer.draw_modality_dropout()
-        if _needs_grad(self):
-            logits, probs, loss = _ModelFn.apply(self, audio, input_ids, labels, drops, *self.parameters())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in arena.params):
+            logits, probs, loss = _ModelFn.apply(self, audio, input_ids, labels, drops, *arena.params)
             return {"loss": loss, "logits": logits, "probabilities": probs}
         return self._infer(audio, input_ids, labels, drops)
 

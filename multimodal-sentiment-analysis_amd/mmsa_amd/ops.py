@@ -938,8 +938,10 @@ def param_norms(flat, table, tnorm, sum_out, chunk_sums_ready=False):
               int(chunk_sums_ready), _stream())
 
 
-def l2_grad_add(gflat, pflat, tnorm, lam, table):
-    _lib.call("mmsa_l2_grad_add", _chk(gflat), _chk(pflat), _chk(tnorm), float(lam), _chk(table.chunk_off, torch.int64),
+def l2_grad_add(gflat, pflat, tnorm, lam, table, scale=None):
+    """gflat += lam * scale * p / ||p|| per tensor; ``scale``: optional one-element device tensor."""
+    _lib.call("mmsa_l2_grad_add", _chk(gflat), _chk(pflat), _chk(tnorm), float(lam), _opt(scale),
+              _chk(table.chunk_off, torch.int64),
               _chk(table.chunk_len, torch.int32), _chk(table.chunk_tensor, torch.int32), table.nchunks, _stream())
 
 

@@ -37,6 +37,12 @@ def text_forward(m, input_ids: torch.Tensor, need_grad: bool, ws: Workspace):
     # workspace creates it zeroed once; check_ids reads and clears it)
     st.err = ws.buf("text.err", 1, torch.int32, zero=not ws.persistent)
     ops.embedding_gather(ids, table, st.emb, st.err)
+    probe = ws.objs.get("text.err_probe")
+    if probe is not None:
+        # the flag as the gather left it goes to pinned host memory at once, with an event behind it: the caller can
+        # look at it when it has enqueued the rest of the forward pass, without waiting for that pass to finish
+        probe[0].copy_(st.err, non_blocking=True)
+        probe[1].record()
     st.pad = m.embedding.padding_idx if m.embedding.padding_idx is not None else -1
     n = len(ksizes)
     st.feat = ws.buf("text.feat", (B, n * F))
@@ -77,6 +83,15 @@ def check_ids(err: torch.Tensor):
     the table.  Reads one int from the device (synchronises)."""
     if int(err.item()):
         err.zero_()
+        raise IndexError("index out of range in self")
+
+
+def check_ids_probe(probe):
+    """The same from the copy that text_forward left in pinned host memory behind the gather (``probe``: the pinned
+    int and the event recorded behind its copy).  Waits for the gather only."""
+    probe[1].synchronize()
+    if int(probe[0][0]):
+        probe[0].zero_()
         raise IndexError("index out of range in self")
 
 
