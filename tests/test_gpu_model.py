@@ -435,3 +435,44 @@ def test_exchanging_the_output_layer_of_a_model_that_has_already_run():
         # one); a gradient written through stale storage would be wrong by its own size.  2e-5: the convolution
         # biases in front of a BatchNorm have an exactly-zero true gradient, both sides return rounding noise
         assert err <= 5e-3 * float(torch.linalg.vector_norm(r)) + 2e-5, f"{k}: {err:.2e}"
+
+
+def test_inputs_in_other_layouts_dtypes_and_places():
+    """What a loader may hand over instead of contiguous float32 / int64 device tensors: a column slice of a wider id
+    matrix, int32 ids, a strided spectrogram view, float64 spectrograms, host tensors, a spectrogram without its channel
+    axis, torch.inference_mode() -- same logits bit for bit; under grad mode the same gradients; TrainStep in graph mode
+    takes them too."""
+    from mmsa_amd.trainer import TrainStep
+    m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).eval()
+    b = batch_tensors(3, 6, vocab=SMALL_VOCAB, device=DEV)
+    wide = torch.zeros(6, 256, dtype=torch.int64, device=DEV)
+    wide[:, :128] = b["input_ids"]
+    big = torch.zeros(6, 1, 64, 260, device=DEV)
+    big[..., ::2] = b["audio"]
+    variants = {
+        "id slice": dict(audio=b["audio"], input_ids=wide[:, :128]),
+        "int32 ids": dict(audio=b["audio"], input_ids=b["input_ids"].int()),
+        "strided audio": dict(audio=big[..., ::2], input_ids=b["input_ids"]),
+        "float64 audio": dict(audio=b["audio"].double(), input_ids=b["input_ids"]),
+        "host tensors": dict(audio=b["audio"].cpu(), input_ids=b["input_ids"].cpu()),
+        "no channel axis": dict(audio=b["audio"][:, 0], input_ids=b["input_ids"]),
+    }
+    with torch.no_grad():
+        ref = m(**model_inputs("both", b))["logits"].clone()
+        for name, kw in variants.items():
+            assert torch.equal(m(**kw)["logits"], ref), name
+    with torch.inference_mode():
+        assert torch.equal(m(**model_inputs("both", b))["logits"], ref)
+    m.train()
+    m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+    m(**model_inputs("both", b), labels=b["label"])["loss"].backward()
+    g0 = [p.grad.clone() for p in m.parameters()]
+    for name, kw in variants.items():
+        m.zero_grad()
+        m(labels=b["label"], **kw)["loss"].backward()
+        assert all(torch.equal(p.grad, g) for p, g in zip(m.parameters(), g0)), name
+    ts = TrainStep(m, use_graph=True)
+    for i in range(4):
+        loss = ts.step(audio=big[..., ::2], input_ids=wide[:, :128].int() if i % 2 else wide[:, :128],
+                       labels=b["label"].int() if i == 3 else b["label"])
+    assert ts._graph is not None and bool(torch.isfinite(loss))
