@@ -184,6 +184,32 @@ def test_audio_transform_applies_the_noise_gate_by_default():
     assert float((off - spec).abs().max()) > 0.1
 
 
+@pytest.mark.parametrize("C,n,sr", [(2, 154350, 44100), (1, 16000, 8000), (2, 44100, 11025), (1, 66151, 22050),
+                                    (3, 3200, 16000), (1, 160000, 32000)])
+def test_audio_transform_at_other_rates_channel_counts_and_lengths(C, n, sr):
+    """The per-utterance call of preprocess.py:125-168 on what a corpus other than the reference's may hold: other
+    sample rates (up- and down-sampling), one to three channels, 0.2 s to 5 s -- against the oracle chain; and the same
+    utterance handed over as a 1-D, float64, device-resident or strided tensor gives the same bits."""
+    from mmsa_amd.frontend import AudioTransform
+    from oracle import denoise_ref, frontend_ref, resample_ref
+    y = _noisy_speechlike(C, n, 7)
+    mono = y.mean(axis=0, dtype=np.float32)
+    res = resample_ref.resample(mono, sr, 22050, np.float64).astype(np.float32) if sr != 22050 else mono
+    den = denoise_ref.reduce_noise(res, 22050)
+    w = np.zeros(66150, np.float32)
+    k = min(66150, len(den))
+    w[:k] = den[:k]
+    tf = AudioTransform(device=DEV, strict=True)
+    spec = tf(torch.from_numpy(y), sr)
+    assert spec.shape == (1, 64, 130)
+    check(spec, torch.from_numpy(frontend_ref.logmel_f64(w[None]))[0], 5e-4)
+    same = [torch.from_numpy(y).double(), torch.from_numpy(y).to(DEV), torch.from_numpy(np.repeat(y, 2, axis=1))[:, ::2]]
+    if C == 1:
+        same.append(torch.from_numpy(y[0]))
+    for other in same:
+        assert torch.equal(tf(other, sr), spec)
+
+
 @pytest.mark.parametrize("augment", [False, True])
 @pytest.mark.parametrize("noise_reduce", [False, True])
 def test_batch_front_end_equals_the_per_utterance_transform(augment, noise_reduce):
