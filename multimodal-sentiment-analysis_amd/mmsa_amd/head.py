@@ -179,6 +179,13 @@ def head_backward_both(model, st, dlogits, grads: Grads, ws: Workspace):
         "dtn_g": g(fn.text_norm.weight), "dtn_b": g(fn.text_norm.bias), "dt_scale": g(fn.text_scale),
     })
     table = ops.head_both_table(t)
+    if not ws.persistent:
+        # autograd path: the gradient tensors are needed as addresses only, and the table has them.  Letting go of them
+        # here leaves autograd the sole owner of what it is handed, so it adopts the tensors instead of copying them
+        for k in ("dwpa", "dbpa", "dgpa", "dbepa", "dwpt", "dbpt", "dgpt", "dbept", "dwatt", "dbatt", "dw0", "db0", "dg0",
+                  "dbe0", "dw1", "db1", "dg1", "dbe1", "dw2", "db2", "dan_g", "dan_b", "da_scale", "dtn_g", "dtn_b",
+                  "dt_scale"):
+            del t[k]
     ops.head_both("bwd", table, st.dims, st.p, st.seed)
     # the parameter gradients only feed the optimiser: helper stream 2 (joined at the end of the step), enqueued by
     # the caller through st.side_work once the data-gradient chain has been launched
