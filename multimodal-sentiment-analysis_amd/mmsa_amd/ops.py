@@ -58,7 +58,14 @@ def _igemm_name(bm, bn, stats, accum, geom, kchunks, nproblems=1, bnrelu=False, 
                                                             "true" if bnrelu else "false")
 
 
+# the raw handle of the current stream without building a torch.cuda.Stream object around it (this is asked once per
+# launch: a launch sequence issued eagerly spends more time here than in the launches otherwise)
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
