@@ -826,6 +826,12 @@ class MultimodalSentimentModel(nn.Module):
     def forward(self, audio=None, input_ids=None, attention_mask=None, labels=None):
         self._check_inputs(audio, input_ids)
         arena = self._ensure_arena()
+        # kernels are launched on the current device: make that the model's for the duration of the call (a model moved
+        # to cuda:1 in a process that never called torch.cuda.set_device)
+        with torch.cuda.device(arena.device):
+            return self._forward_on_device(arena, audio, input_ids, labels)
+
+    def _forward_on_device(self, arena, audio, input_ids, labels):
         dev = arena.device
         if audio is not None and self.modality != "text":
             _refuse_spectrogram_grad(audio)

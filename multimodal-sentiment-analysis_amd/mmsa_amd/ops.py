@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import threading
 from typing import List, Optional, Sequence
 
 import torch
@@ -63,9 +64,23 @@ def _igemm_name(bm, bn, stats, accum, geom, kchunks, nproblems=1, bnrelu=False, 
 _RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+# device of the operands of the launch that is being put together (per thread: autograd runs backward passes on
+# threads of its own)
+_OPERANDS = threading.local()
+
+
 def _stream() -> int:
+    """Raw handle of the current stream -- of the CURRENT device, which is also where the runtime launches.  Operands
+    on another device (a model moved to cuda:1 in a process whose current device is still cuda:0) would be handed to a
+    kernel on the wrong GPU: refused here, by name, instead of faulting there."""
+    cur = torch.cuda.current_device()
+    dev = getattr(_OPERANDS, "dev", cur)
+    if dev != cur:
+        raise _lib.MmsaError(f"operands live on cuda:{dev} but the current device is cuda:{cur}: call "
+                             f"torch.cuda.set_device({dev}) (one process per GPU) or wrap the call in "
+                             f"torch.cuda.device({dev})")
     if _RAW_STREAM is not None:
-        return _RAW_STREAM(torch.cuda.current_device())
+        return _RAW_STREAM(cur)
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -76,6 +91,7 @@ def _chk(t: torch.Tensor, dtype=F32, name: str = "tensor") -> int:
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError(f"{name} must be contiguous")
+    _OPERANDS.dev = t.get_device()
     return t.data_ptr()
 
 

@@ -261,6 +261,11 @@ class TrainStep:
     # ------------------------------------------------------------------ public API
     def step(self, audio=None, input_ids=None, labels=None, wave=None):
         """Runs one optimisation step.  Returns the device tensor holding the loss (no host sync)."""
+        # kernels are launched on the current device: the model's, for the duration of the step
+        with torch.cuda.device(self.arena.device):
+            return self._step(audio, input_ids, labels, wave)
+
+    def _step(self, audio, input_ids, labels, wave):
         model = self.model
         if labels is None:
             raise ValueError("labels are required for a training step")

@@ -867,3 +867,17 @@ def test_squeeze_excite_gate_inside_the_pooling_launch(B, H, W, C, mean):
     assert torch.equal(out, want)
     for a, b in zip(got, ref):
         assert torch.equal(a, b)
+
+
+def test_operands_on_another_device_than_the_current_one_are_refused(monkeypatch):
+    """Kernels launch on the current device.  A process that drives several GPUs and hands over tensors of a device
+    that is not current would run a kernel on the wrong GPU: the binding refuses by name instead.  (One GPU here: the
+    current device is faked.)  The model's forward and TrainStep.step make their device current themselves."""
+    from mmsa_amd import _lib, ops
+    x = torch.zeros(4, 8, device=DEV)
+    ops._chk(x)
+    assert ops._stream() == torch.cuda.current_stream().cuda_stream
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)
+    ops._chk(x)
+    with pytest.raises(_lib.MmsaError, match="current device"):
+        ops._stream()
