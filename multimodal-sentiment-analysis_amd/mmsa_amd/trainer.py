@@ -275,6 +275,7 @@ class TrainStep:
             raise RuntimeError("TrainStep.step() needs model.train()")
         if self.lr_from is not None:
             self.set_lr(self.lr_from.param_groups[0]["lr"])
+        self._check_storage(full=self._graph is None or self._nstep % self.CHECK_EVERY == 0)
         # parameter sums left by the previous step stay valid only if nobody else wrote the parameters since
         # (load_state_dict, a user optimiser, ...): torch's version counters tell
         pv = sum(p._version for p in self.arena.params)
@@ -397,6 +398,23 @@ class TrainStep:
         return self.loss
 
     CHECK_EVERY = 256
+
+    def _check_storage(self, full: bool):
+        """The step updates the flat buffer the model's parameters lived in when this object was built.  After
+        ``model.to(...)`` / ``.float()`` (every parameter re-allocated) or an exchanged layer (other Parameter objects)
+        they live elsewhere, and the update would move numbers nobody reads: refuse.  Cheap form on every step (the
+        model still points at this storage, the first tensor still sits at its start), the walk over all tensors before
+        a capture, on eagerly launched steps and every CHECK_EVERY replayed ones."""
+        a = self.arena
+        ok = self.model.__dict__.get("_arena") is a and a.params[0].data_ptr() == a.flat.data_ptr()
+        if ok and full:
+            cur = list(self.model.parameters())
+            ok = len(cur) == len(a.params) and all(x is y for x, y in zip(cur, a.params)) and a.owns()
+        if not ok:
+            raise RuntimeError("the model's parameters no longer live in the storage this TrainStep updates (the model "
+                               "was moved or converted, or a layer was exchanged, after the TrainStep was built): "
+                               "build a new TrainStep, carrying the optimiser state over with state_dict() / "
+                               "load_state_dict()")
 
     def check_ids(self):
         """Raises IndexError if any step since the last call saw a token id outside the embedding table (those

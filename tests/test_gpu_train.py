@@ -666,3 +666,35 @@ def test_token_id_outside_the_table_raises_and_touches_no_neighbouring_gradient(
             ts.step(audio=b["audio"], input_ids=good, labels=b["label"])
         ts.step(audio=b["audio"], input_ids=good, labels=b["label"])        # the flag was cleared by the raise
         ts.state_dict()
+
+
+def test_train_step_refuses_a_model_whose_parameters_moved_away():
+    """TrainStep updates the flat storage the parameters lived in when it was built.  A model moved through host
+    memory, or with an exchanged layer, has its parameters elsewhere: the step would train numbers nobody reads, so it
+    refuses -- before and after a forward pass of the model has re-homed them -- and a new TrainStep takes over the
+    optimiser state."""
+    from mmsa_amd.trainer import TrainStep
+    b = batch_tensors(0, 8, vocab=SMALL_VOCAB, device=DEV)
+    for how in ("moved", "moved, then used", "layer exchanged"):
+        for use_graph in (False, True):
+            m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+            ts = TrainStep(m, use_graph=use_graph)
+            for _ in range(4):
+                ts.step(**_step_inputs("both", b))
+            if how == "layer exchanged":
+                m.classifier[len(m.classifier) - 1] = torch.nn.Linear(64, 3).to(DEV)
+            else:
+                m.cpu().to(DEV)
+                if how == "moved, then used":
+                    with torch.no_grad():
+                        m(audio=b["audio"], input_ids=b["input_ids"])
+            with pytest.raises(RuntimeError, match="build a new TrainStep"):
+                for _ in range(TrainStep.CHECK_EVERY + 1):       # a replayed step may take until the next full check
+                    ts.step(**_step_inputs("both", b))
+            if how != "layer exchanged":
+                sd = ts.state_dict()
+                ts2 = TrainStep(m, use_graph=use_graph)
+                ts2.load_state_dict(sd)
+                before = m._arena.flat.clone()
+                ts2.step(**_step_inputs("both", b))
+                assert not torch.equal(before, m._arena.flat)
