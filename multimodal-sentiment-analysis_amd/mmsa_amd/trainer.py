@@ -77,6 +77,7 @@ class TrainStep:
         self._keep_table = torch.tensor([[1., 1.], [0., 1.], [1., 0.], [0., 0.]], device=dev)
         self.use_graph = use_graph
         self._graph = None
+        self._baked = None
         self._norms_ready = False      # True once AdamW has left current per-chunk parameter sums behind
         self._pversion = None
         self._static = {}
@@ -275,6 +276,8 @@ class TrainStep:
             raise RuntimeError("TrainStep.step() needs model.train()")
         if self.lr_from is not None:
             self.set_lr(self.lr_from.param_groups[0]["lr"])
+        if self._graph is not None and self._baked != self._scalars():
+            self._graph = None      # an optimiser scalar was assigned to since the capture, which holds the old value
         self._check_storage(full=self._graph is None or self._nstep % self.CHECK_EVERY == 0)
         # parameter sums left by the previous step stay valid only if nobody else wrote the parameters since
         # (load_state_dict, a user optimiser, ...): torch's version counters tell
@@ -354,6 +357,7 @@ class TrainStep:
                 self._body(*args)
                 return self.loss
             torch.cuda.synchronize()
+            self._baked = self._scalars()
             g = torch.cuda.CUDAGraph()
             if not self.dist:
                 with torch.cuda.graph(g, capture_error_mode=CAPTURE_MODE):
@@ -398,6 +402,11 @@ class TrainStep:
         return self.loss
 
     CHECK_EVERY = 256
+
+    def _scalars(self):
+        """What a captured step holds by value."""
+        return (float(self.lr), float(self.wd), float(self.eps), tuple(float(b) for b in self.betas),
+                None if self.max_norm is None else float(self.max_norm))
 
     def _check_storage(self, full: bool):
         """The step updates the flat buffer the model's parameters lived in when this object was built.  After

@@ -125,9 +125,15 @@ def test_learning_rate_change_between_replayed_steps():
             if s == 7 and use_graph:
                 assert ts._graph is g_before
         assert ts.state_dict()["param_groups"][0]["lr"] == 2.5e-4
+        # the other scalars a captured step holds by value: assigning to them takes effect too
+        ts.wd, ts.max_norm = 0.05, 0.5
+        for s in range(9, 12):
+            b = batch_tensors(8 * s, 8, vocab=SMALL_VOCAB)
+            losses.append(ts.step(**_step_inputs("both", {k: v.to(DEV) for k, v in b.items()})).clone())
+        assert float(ts.grad_norm()) > 0.5          # the clip threshold in force is the new one ...
         res.append((torch.stack([x.reshape(()) for x in losses]), m._arena.flat.clone()))
     assert torch.equal(res[0][0], res[1][0]), (res[0][0] - res[1][0]).abs()
-    assert torch.equal(res[0][1], res[1][1])
+    assert torch.equal(res[0][1], res[1][1])         # ... and the replayed run equals the eager one with it
 
 
 def test_reference_scheduler_drives_the_step_through_a_carrier_optimizer():
