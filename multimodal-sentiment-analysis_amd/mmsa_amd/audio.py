@@ -105,6 +105,30 @@ def _bn_args(bn):
     return bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked
 
 
+def _one_mode(flags, what: str) -> bool:
+    flags = set(flags)
+    if len(flags) > 1:
+        raise NotImplementedError(f"{what}: some BatchNorm layers are in training mode and some in eval mode; the HIP "
+                                  "kernels run all of them one way")
+    return flags.pop()
+
+
+def block_bn_training(blk) -> bool:
+    """Whether a ResidualBlock's BatchNorm layers use batch statistics.  It is their own ``training`` flags that
+    decide, as in torch: the usual way to freeze BatchNorm (``.eval()`` on the BatchNorm modules of a model that is
+    otherwise in training mode) leaves the enclosing modules' flags alone."""
+    flags = [blk.bn1.training, blk.bn2.training]
+    if len(blk.shortcut) > 0:
+        flags.append(blk.shortcut[1].training)
+    return _one_mode(flags, "ResidualBlock")
+
+
+def bn_training(m) -> bool:
+    """The same for the whole audio branch (stem + three blocks: ten layers)."""
+    return _one_mode([m.conv1[1].training] + [block_bn_training(b) for b in (m.res_block1, m.res_block2, m.res_block3)],
+                     "AudioModel")
+
+
 def _pack_bufs(ws: Workspace, name: str, w: torch.Tensor, need_dgrad: bool):
     f = ws.buf(name + ".wf", w.numel())
     d = ws.buf(name + ".wd", w.numel()) if need_dgrad else None

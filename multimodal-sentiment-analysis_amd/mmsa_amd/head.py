@@ -268,7 +268,9 @@ def head_forward_audio(model, feat, labels, training, drop_p, seed, need_grad, w
     cl = model.classifier
     p = drop_p if training else 0.0
     step = step_state if p > 0 else None
-    st = SimpleNamespace(kind="audio", B=B, feat=feat, training=training, p=p, seed=seed, step=step)
+    # (the two BatchNorm1d layers go by their own flags, as in torch; dropout by the model's)
+    st = SimpleNamespace(kind="audio", B=B, feat=feat, training=training, p=p, seed=seed, step=step,
+                         bn_training=(cl[2].training, cl[6].training))
     st.l1 = _Dense(ws, "head.a1", cl[1], None, EPI_NONE, B)
     st.l2 = _Dense(ws, "head.a5", cl[5], None, EPI_NONE, B)
     st.l3 = _Dense(ws, "head.a9", cl[9], None, EPI_NONE, B)
@@ -276,14 +278,14 @@ def head_forward_audio(model, feat, labels, training, drop_p, seed, need_grad, w
     st.y1 = ws.buf("head.y1", st.z1.shape)
     st.cf1 = ws.buf("head.cf1", 4 * st.z1.shape[1])
     bn = cl[2]
-    ops.bn1d_relu_fwd(st.z1, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, training,
-                      st.y1, st.cf1, p, seed + 1, step)
+    ops.bn1d_relu_fwd(st.z1, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                      st.bn_training[0], st.y1, st.cf1, p, seed + 1, step)
     st.z2 = st.l2.fwd(st.y1, ws.buf("head.z2", (B, cl[5].weight.shape[0])))
     st.y2 = ws.buf("head.y2", st.z2.shape)
     st.cf2 = ws.buf("head.cf2", 4 * st.z2.shape[1])
     bn = cl[6]
-    ops.bn1d_relu_fwd(st.z2, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, training,
-                      st.y2, st.cf2, p / 2, seed + 2, step)
+    ops.bn1d_relu_fwd(st.z2, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                      st.bn_training[1], st.y2, st.cf2, p / 2, seed + 2, step)
     logits = st.l3.fwd(st.y2, logits_out if logits_out is not None else ws.buf("head.logits", (B, cl[9].weight.shape[0])))
     return _finish(st, ws, logits, labels, B, need_grad)
 
@@ -294,12 +296,12 @@ def head_backward_audio(model, st, dlogits, grads: Grads, ws: Workspace):
     dy2 = ws.buf("head.dy2", st.y2.shape)
     st.l3.bwd(ws, dlogits, dy2, grads)
     dz2 = ws.buf("head.dz2", st.z2.shape)
-    ops.bn1d_relu_bwd(dy2, st.z2, st.cf2, dz2, grads.of(cl[6].weight), grads.of(cl[6].bias), st.training, st.p / 2,
-                      st.seed + 2, st.step)
+    ops.bn1d_relu_bwd(dy2, st.z2, st.cf2, dz2, grads.of(cl[6].weight), grads.of(cl[6].bias), st.bn_training[1],
+                      st.p / 2, st.seed + 2, st.step)
     dy1 = ws.buf("head.dy1", st.y1.shape)
     st.l2.bwd(ws, dz2, dy1, grads)
     dz1 = ws.buf("head.dz1", st.z1.shape)
-    ops.bn1d_relu_bwd(dy1, st.z1, st.cf1, dz1, grads.of(cl[2].weight), grads.of(cl[2].bias), st.training, st.p,
+    ops.bn1d_relu_bwd(dy1, st.z1, st.cf1, dz1, grads.of(cl[2].weight), grads.of(cl[2].bias), st.bn_training[0], st.p,
                       st.seed + 1, st.step)
     dfeat = ws.buf("head.dfeat", st.feat.shape)
     st.l1.bwd(ws, dz1, dfeat, grads)

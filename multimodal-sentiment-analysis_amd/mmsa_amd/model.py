@@ -209,7 +209,7 @@ class _ResidualBlockFn(torch.autograd.Function):
         B, H, W, Cin = xl.shape
         Cout = m.conv1.weight.shape[0]
         K = torch.ops.mmsa
-        training = m.training
+        training = audio_engine.block_bn_training(m)
         project = len(m.shortcut) > 0
         npos = B * H * W
         packs = {}
@@ -324,12 +324,14 @@ class _BranchFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, inp, *params):
         ws = Workspace(inp.device, persistent=False)
+        training = module.training
         if isinstance(module, AudioModel):
-            feat, st = audio_engine.audio_forward(module, inp, module.training, True, ws)
+            training = audio_engine.bn_training(module)
+            feat, st = audio_engine.audio_forward(module, inp, training, True, ws)
         else:
             feat, st = text_engine.text_forward(module, inp, True, ws)
             text_engine.check_ids(st.err)
-        ctx.module, ctx.st, ctx.ws, ctx.training = module, st, ws, module.training
+        ctx.module, ctx.st, ctx.ws, ctx.training = module, st, ws, training
         ctx.set_materialize_grads(False)
         return feat.clone()
 
@@ -381,7 +383,7 @@ class AudioModel(nn.Module):
         if _needs_grad(self):
             return _BranchFn.apply(self, x, *self.parameters())
         ws = self.__dict__.setdefault("_ws", Workspace(dev))
-        feat, _ = audio_engine.audio_forward(self, x, self.training, False, ws)
+        feat, _ = audio_engine.audio_forward(self, x, audio_engine.bn_training(self), False, ws)
         return feat.clone()
 
 
@@ -708,6 +710,8 @@ class MultimodalSentimentModel(nn.Module):
         arena = self._arena
         training = self.training
         run = SimpleNamespace(audio=None, text=None, l2=False, touched=set())
+        # the branch's BatchNorm layers decide by their own flags (kept for the backward pass of this forward pass)
+        run.audio_training = audio_engine.bn_training(self.audio_model) if self.audio_model is not None else False
         a_feat = t_feat = None
         if self.modality == "both":
             # the two branches are independent until the head: the (small) text branch runs on a helper stream; it is
@@ -729,13 +733,13 @@ class MultimodalSentimentModel(nn.Module):
                 return None
             if where < 0:
                 text_branch()
-            a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, self.audio_model.training,
+            a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, run.audio_training,
                                                            need_grad, ws, side_work=(where, text_branch) if where >= 0
                                                            else None)
             t_feat, run.text = box["out"]
             box["fork"].join()
         elif self.modality == "audio":
-            a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, self.audio_model.training,
+            a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, run.audio_training,
                                                            need_grad, ws)
         else:
             t_feat, run.text = text_engine.text_forward(self.text_model, input_ids, need_grad, ws)
@@ -800,7 +804,7 @@ class MultimodalSentimentModel(nn.Module):
             audio_engine.fork(ws, dev, 2).join()
             return
         if phase == "late":
-            audio_engine.audio_backward(self.audio_model, run.audio, run.d_audio, self.audio_model.training, grads, ws)
+            audio_engine.audio_backward(self.audio_model, run.audio, run.d_audio, run.audio_training, grads, ws)
             return
         if self.modality == "both":
             d_a, d_t = head_engine.head_backward_both(self, run.head, dlogits, grads, ws)
@@ -810,11 +814,11 @@ class MultimodalSentimentModel(nn.Module):
             with audio_engine.fork(ws, dev, 1) as f:
                 text_engine.text_backward(self.text_model, run.text, d_t, grads, ws)
             side_work()
-            audio_engine.audio_backward(self.audio_model, run.audio, d_a, self.audio_model.training, grads, ws)
+            audio_engine.audio_backward(self.audio_model, run.audio, d_a, run.audio_training, grads, ws)
             f.join()
         elif self.modality == "audio":
             d_a = head_engine.head_backward_audio(self, run.head, dlogits, grads, ws)
-            audio_engine.audio_backward(self.audio_model, run.audio, d_a, self.audio_model.training, grads, ws)
+            audio_engine.audio_backward(self.audio_model, run.audio, d_a, run.audio_training, grads, ws)
             side_work()
         else:
             d_t = head_engine.head_backward_text(self, run.head, dlogits, grads, ws)
@@ -855,7 +859,8 @@ class MultimodalSentimentModel(nn.Module):
         B = audio.shape[0] if audio is not None and self.modality != "text" else input_ids.shape[0]
         ncls = self.classifier[-1].weight.shape[0]
         logits = torch.empty((B, ncls), dtype=torch.float32, device=self._arena.device)
-        chunk = B if self.training else INFER_CHUNK
+        batch_stats = self.training or (self.audio_model is not None and audio_engine.bn_training(self.audio_model))
+        chunk = B if batch_stats else INFER_CHUNK
         run = None
         for i0 in range(0, B, max(chunk, 1)):
             i1 = min(B, i0 + chunk)

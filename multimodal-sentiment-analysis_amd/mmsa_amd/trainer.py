@@ -22,7 +22,7 @@ from typing import Optional
 
 import torch
 
-from . import ops, parallel, text as text_engine
+from . import audio as audio_engine, ops, parallel, text as text_engine
 from .audio import fork
 from .model import L2_LAMBDA, MultimodalSentimentModel
 from .workspace import Grads, Workspace
@@ -404,9 +404,15 @@ class TrainStep:
     CHECK_EVERY = 256
 
     def _scalars(self):
-        """What a captured step holds by value."""
+        """What a captured step holds by value: the optimiser's scalars, the dropout rates, and whether the audio
+        branch's BatchNorm layers use batch statistics (``model.audio_model.eval()`` under a training model freezes
+        them)."""
+        m = self.model
+        bn = None if m.audio_model is None else audio_engine.bn_training(m.audio_model)
+        if m.modality == "audio":
+            bn = (bn, m.classifier[2].training, m.classifier[6].training)
         return (float(self.lr), float(self.wd), float(self.eps), tuple(float(b) for b in self.betas),
-                None if self.max_norm is None else float(self.max_norm))
+                None if self.max_norm is None else float(self.max_norm), tuple(m._dropouts), bn)
 
     def _check_storage(self, full: bool):
         """The step updates the flat buffer the model's parameters lived in when this object was built.  After

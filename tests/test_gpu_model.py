@@ -476,3 +476,55 @@ def test_inputs_in_other_layouts_dtypes_and_places():
         loss = ts.step(audio=big[..., ::2], input_ids=wide[:, :128].int() if i % 2 else wide[:, :128],
                        labels=b["label"].int() if i == 3 else b["label"])
     assert ts._graph is not None and bool(torch.isfinite(loss))
+
+
+@pytest.mark.parametrize("modality", ["audio", "both"])
+def test_frozen_batchnorm_in_a_training_model(modality):
+    """The usual way to freeze BatchNorm while fine-tuning: ``.eval()`` on the BatchNorm modules of a model that is in
+    training mode.  torch lets each BatchNorm layer go by its own flag; so does the drop-in: running statistics in the
+    forward and backward pass, untouched afterwards, in the eager path and in TrainStep -- against the oracle in eval
+    mode (dropout is 0 here, so BatchNorm is all that the mode changes).  A branch frozen halfway is refused."""
+    from mmsa_amd.trainer import TrainStep
+    m = seeded_model(modality, vocab=SMALL_VOCAB).to(DEV).train()
+    with torch.no_grad():
+        for i in range(20):
+            m(**model_inputs(modality, batch_tensors(100 + 8 * i, 8, vocab=SMALL_VOCAB, device=DEV)))
+    if modality == "both":
+        m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+            mod.eval()
+    assert m.training and m.audio_model.training
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    b = batch_tensors(11, 6, vocab=SMALL_VOCAB)
+    bd = {k: v.to(DEV) for k, v in b.items()}
+    out = m(**model_inputs(modality, bd), labels=bd["label"])
+    out["loss"].backward()
+    w = model_ref.clone_state(sd, requires_grad=True)
+    ref = model_ref.forward(w, modality, b["audio"], b["input_ids"] if modality == "both" else None, b["label"],
+                            training=False)
+    ref["loss"].backward()
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 1e-5
+    for k, p in m.named_parameters():
+        r = w[k].grad if w[k].grad is not None else torch.zeros_like(w[k])
+        err = float(torch.linalg.vector_norm(p.grad.cpu() - r))
+        assert err <= 1e-4 * float(torch.linalg.vector_norm(r)) + 1e-7, f"{k}: {err:.2e}"
+    for k, v in m.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(v.cpu(), sd[k]), k
+    # the fused step: same gradient (its norm), statistics still untouched; graph mode follows a later change of mode
+    ts = TrainStep(m, use_graph=True, max_norm=1e9, lr=0.0, weight_decay=0.0)
+    for _ in range(4):
+        ts.step(**{k: v for k, v in (("audio", bd["audio"]), ("input_ids", bd["input_ids"] if modality == "both" else None),
+                                     ("labels", bd["label"])) if v is not None})
+    gn = float(torch.linalg.vector_norm(torch.cat([p.grad.flatten() for p in m.parameters()])))
+    assert abs(float(ts.grad_norm()) - gn) < 1e-4 * gn
+    for k, v in m.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(v.cpu(), sd[k]), k
+    m.train()                                           # every layer back to batch statistics: the step is captured again
+    ts.step(audio=bd["audio"], labels=bd["label"], **({"input_ids": bd["input_ids"]} if modality == "both" else {}))
+    assert not torch.equal(m.state_dict()["audio_model.conv1.1.running_mean"].cpu(), sd["audio_model.conv1.1.running_mean"])
+    m.audio_model.res_block2.bn1.eval()
+    with pytest.raises(NotImplementedError, match="BatchNorm"):
+        m(**model_inputs(modality, bd))
