@@ -710,6 +710,16 @@ class MultimodalSentimentModel(nn.Module):
         arena = self._arena
         training = self.training
         run = SimpleNamespace(audio=None, text=None, l2=False, touched=set())
+        # dropout is applied inside fused kernels that take one rate: the Dropout modules cannot go their own way
+        groups = [self.classifier]
+        if self.modality == "both":
+            groups += [self.fusion_layer.audio_projector, self.fusion_layer.text_projector]
+        for seq in groups:
+            for mod in seq:
+                if isinstance(mod, nn.Dropout) and mod.training != training:
+                    raise NotImplementedError("a Dropout module whose training flag differs from the model's (dropout "
+                                              "at inference, or a single layer switched off): the HIP head applies "
+                                              "dropout by the model's flag")
         # the branch's BatchNorm layers decide by their own flags (kept for the backward pass of this forward pass)
         run.audio_training = audio_engine.bn_training(self.audio_model) if self.audio_model is not None else False
         a_feat = t_feat = None

@@ -528,3 +528,10 @@ def test_frozen_batchnorm_in_a_training_model(modality):
     m.audio_model.res_block2.bn1.eval()
     with pytest.raises(NotImplementedError, match="BatchNorm"):
         m(**model_inputs(modality, bd))
+    # dropout layers switched on in an eval model (Monte-Carlo dropout) cannot be honoured by the fused head: refused
+    m.eval()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.train()
+    with pytest.raises(NotImplementedError, match="Dropout"), torch.no_grad():
+        m(**model_inputs(modality, bd))
