@@ -18,6 +18,7 @@ from types import SimpleNamespace
 
 import torch
 import torch.nn as nn
+from torch.autograd.function import once_differentiable
 
 from . import ops
 from .head import _Dense, _finish
@@ -129,6 +130,7 @@ class _FusionFn(torch.autograd.Function):
         return st.fused.clone(), wts, hs.logits.clone(), hs.probs.clone(), loss
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_fused, g_wts, g_logits, g_probs, g_loss):
         fl, head, st, ws = ctx.fl, ctx.head, ctx.st, ctx.ws
         plist = list(fl.parameters()) + (list(head.classifier.parameters()) if head is not None else [])

@@ -22,6 +22,7 @@ from typing import List, Optional
 
 import torch
 import torch.nn as nn
+from torch.autograd.function import once_differentiable
 
 from . import _lib, audio as audio_engine, head as head_engine, ops, text as text_engine, torch_ops  # noqa: F401
 from .arena import ParamArena
@@ -63,6 +64,7 @@ class _LinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         rows, weight = ctx.saved_tensors
         dy = dy.contiguous()
@@ -146,6 +148,7 @@ class _SEBlockFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         xl, gap, hid, gate, W1, W2 = ctx.saved_tensors
         B, H, W, C = xl.shape
@@ -249,6 +252,7 @@ class _ResidualBlockFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         m = ctx.m
         xl, c1, coeff1, h1, c2, coeff2, bsum2, gap, hid, gate, sc, coeffs, packs, training, project = ctx.st
@@ -336,6 +340,7 @@ class _BranchFn(torch.autograd.Function):
         return feat.clone()
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dfeat):
         m = ctx.module
         plist = list(m.parameters())
@@ -453,6 +458,7 @@ class _NormalizerFn(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dya, dyt):
         m = ctx.m
         xa, sa, xt, st = ctx.saved_tensors
@@ -532,6 +538,7 @@ class _FusionFn(torch.autograd.Function):
         return fused
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dfused):
         m = ctx.m
         ws, pa, pt, att, P, wts, drop_a, drop_t = ctx.st
@@ -585,6 +592,7 @@ class _ModelFn(torch.autograd.Function):
         return run.head.logits.clone(), run.head.probs.clone(), loss
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, g_logits, g_probs, g_loss):
         model, run, arena = ctx.model, ctx.run, ctx.arena
         plist = arena.params
@@ -847,6 +855,15 @@ class MultimodalSentimentModel(nn.Module):
 
     def _forward_on_device(self, arena, audio, input_ids, labels):
         dev = arena.device
+        # the model runs as one launch sequence: the sub-modules' own forward methods are not called, so hooks
+        # registered on them would silently never fire
+        for child in (self.audio_model, self.text_model, self.__dict__["_modules"].get("feature_normalizer"),
+                      self.__dict__["_modules"].get("fusion_layer"), self.classifier):
+            if child is not None and (child._forward_hooks or child._forward_pre_hooks or child._backward_hooks
+                                      or child._backward_pre_hooks):
+                raise NotImplementedError("hooks on a sub-module of MultimodalSentimentModel do not fire (the model runs "
+                                          "as one fused launch sequence): hook the model itself, or call the "
+                                          "sub-module on its own -- each has a stand-alone forward")
         if audio is not None and self.modality != "text":
             _refuse_spectrogram_grad(audio)
             audio = audio.to(device=dev, dtype=torch.float32)

@@ -535,3 +535,26 @@ def test_frozen_batchnorm_in_a_training_model(modality):
             mod.train()
     with pytest.raises(NotImplementedError, match="Dropout"), torch.no_grad():
         m(**model_inputs(modality, bd))
+
+
+def test_what_the_fused_model_cannot_honour_is_refused_not_ignored():
+    """Hooks on sub-modules (their forward methods are never called inside the fused model) and differentiating the
+    gradient a second time (gradient penalties): torch would do both; the drop-in says that it does not."""
+    m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+    b = batch_tensors(3, 4, vocab=SMALL_VOCAB, device=DEV)
+    seen = []
+    top = m.register_forward_hook(lambda mod, args, out: seen.append(out["logits"].shape))
+    m(**model_inputs("both", b))
+    assert seen == [(4, 3)]                                # a hook on the model itself fires as usual
+    top.remove()
+    h = m.audio_model.register_forward_hook(lambda mod, args, out: seen.append(out.shape))
+    with pytest.raises(NotImplementedError, match="hooks"):
+        m(**model_inputs("both", b))
+    h.remove()
+    feats = m.audio_model(b["audio"])                      # the sub-module on its own is the way to its features
+    assert feats.shape == (4, 256)
+    out = m(**model_inputs("both", b), labels=b["label"])
+    (g,) = torch.autograd.grad(out["loss"], [m.classifier[0].weight], create_graph=True)
+    assert g.grad_fn is None                               # no graph hangs on the gradient: a penalty on it cannot be
+    with pytest.raises(RuntimeError, match="does not require grad|once_differentiable"):     # differentiated, and says so
+        g.square().sum().backward()
