@@ -579,6 +579,39 @@ def test_single_rank_process_group_path_equals_plain_step(overlap, monkeypatch):
         dist.destroy_process_group()
 
 
+def test_drop_in_model_inside_distributed_data_parallel():
+    """The reference-style alternative to TrainStep's own data-parallel mode: the drop-in model wrapped in torch's
+    DistributedDataParallel, whose reducer hangs hooks on every parameter's gradient accumulator and takes the gradients
+    as the one autograd node of the fused model hands them over.  One rank over RCCL: losses and parameters equal the
+    unwrapped run bit for bit."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    port = 29800 + (os.getpid() % 200)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda:0"))
+    try:
+        res = []
+        for wrap in (False, True):
+            m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+            m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+            net = DistributedDataParallel(m, device_ids=[0]) if wrap else m
+            opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-4)
+            losses = []
+            for s in range(4):
+                b = batch_tensors(8 * s, 8, vocab=SMALL_VOCAB, device=DEV)
+                opt.zero_grad()
+                out = net(audio=b["audio"], input_ids=b["input_ids"], labels=b["label"])
+                out["loss"].backward()
+                torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+                opt.step()
+                losses.append(float(out["loss"].detach()))
+            res.append((losses, m._arena.flat.clone()))
+        assert res[0][0] == res[1][0]
+        assert torch.equal(res[0][1], res[1][1])
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.parametrize("modality,act,dact", [("both", "head.h1", "head.c0.dln"), ("text", "head.h1", "head.t1.dln"),
                                                ("audio", "head.y1", None)])
 def test_graph_replay_draws_new_dropout_masks(modality, act, dact):
