@@ -368,6 +368,10 @@ MMSA_API int mmsa_pair_attn_mix_bwd(const float* dWm, const float* M, const floa
 MMSA_API int mmsa_gate_mix_fwd(const float* Wm, const float* gate, float* fused, int B, int Fd, void* stream);
 MMSA_API int mmsa_gate_mix_bwd(const float* dfused, const float* Wm, const float* gate, float* dWm, float* dgate, int B,
                                int Fd, int accumulate, void* stream);
+/* what nn.CrossEntropyLoss checks before it computes (:452-454; "Target N is out of bounds"): raises bit 1 of the
+   sticky flag word *err when a label lies outside [0, C) (bit 0 is the embedding gather's: a token id outside the
+   table); the host turns the flag into the reference's IndexError */
+MMSA_API int mmsa_check_labels(const long long* labels, int B, int C, int* err, void* stream);
 /* probabilities, mean cross-entropy and d(loss)/d(logits) = (p - onehot)/B   (:449-454) */
 MMSA_API int mmsa_softmax_ce(const float* logits, const long long* labels, float* probs, float* loss, float* dlogits,
                              int B, int C, void* stream);

@@ -680,6 +680,25 @@ MMSA_EXPORT int mmsa_fusion_mix_bwd(const float* dfused, const float* P, const f
   return mmsa_launch_status();
 }
 
+// Raises bit 1 of the sticky flag word `err` when a class label lies outside [0, C): the loss kernels treat such a row
+// as having no target (no term in the loss, no -1 in the gradient), where torch's CrossEntropyLoss refuses it.  (Bit 0
+// of the same word belongs to the embedding gather: a token id outside the table.)
+__global__ __launch_bounds__(256) void check_labels_kernel(const long long* __restrict__ labels, int B, int C,
+                                                           int* __restrict__ err) {
+  bool bad = false;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const long long y = labels[b];
+    bad |= y < 0 || y >= C;
+  }
+  if (bad) atomicOr(err, 2);
+}
+
+MMSA_EXPORT int mmsa_check_labels(const long long* labels, int B, int C, int* err, void* stream) {
+  MMSA_REQUIRE(labels && err && B > 0 && C > 0);
+  hipLaunchKernelGGL(check_labels_kernel, dim3(1), dim3(256), 0, mmsa_stream(stream), labels, B, C, err);
+  return mmsa_launch_status();
+}
+
 // labels may be null (inference): probabilities only.  loss / dlogits optional.
 MMSA_EXPORT int mmsa_softmax_ce(const float* logits, const long long* labels, float* probs, float* loss, float* dlogits,
                                 int B, int C, void* stream) {

@@ -580,11 +580,11 @@ class _ModelFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, audio, input_ids, labels, drops, *params):
         ws = Workspace(params[0].device, False)
-        if model.text_model is not None:
-            ws.objs["text.err_probe"] = _ids_probe(model, params[0].device)
+        ws.objs["text.err_probe"] = _ids_probe(model, params[0].device)
         run = model._run(audio, input_ids, labels, drops, need_grad=True, ws=ws)
-        if run.text is not None:
-            # raises IndexError like the reference's nn.Embedding, having waited for the gather, not for the pass
+        if run.text is not None or run.err is not None:
+            # raises IndexError like the reference's nn.Embedding / nn.CrossEntropyLoss, having waited for the head of
+            # the pass (label check, gather), not for the pass
             text_engine.check_ids_probe(ws.objs["text.err_probe"])
         ctx.model, ctx.run, ctx.arena = model, run, model._arena
         ctx.set_materialize_grads(False)
@@ -731,6 +731,21 @@ class MultimodalSentimentModel(nn.Module):
         # the branch's BatchNorm layers decide by their own flags (kept for the backward pass of this forward pass)
         run.audio_training = audio_engine.bn_training(self.audio_model) if self.audio_model is not None else False
         a_feat = t_feat = None
+        # A class label outside [0, C) is an IndexError in the reference (nn.CrossEntropyLoss); the loss kernels would
+        # treat such a row as one without a target.  One small launch at the head of the pass -- for 'both' on the text
+        # branch's stream -- raises bit 1 of the sticky flag word whose bit 0 belongs to the token ids; the callers
+        # turn the flag into the error.
+        run.err = None
+        if labels is not None:
+            labels = labels.contiguous()
+            if labels.dtype != torch.int64:
+                labels = labels.to(torch.int64)
+            run.err = ws.buf("text.err", 1, torch.int32, zero=not ws.persistent)
+            ncls = self.classifier[len(self.classifier) - 1].weight.shape[0]
+
+        def label_check():
+            if run.err is not None:
+                ops.check_labels(labels, ncls, run.err)
         if self.modality == "both":
             # the two branches are independent until the head: the (small) text branch runs on a helper stream; it is
             # enqueued first so that it starts beside the stem instead of colliding with the last block's convolutions
@@ -743,7 +758,8 @@ class MultimodalSentimentModel(nn.Module):
 
                 def body():
                     with fk:
-                        box["out"] = text_engine.text_forward(self.text_model, input_ids, need_grad, ws)
+                        label_check()
+                        box["out"] = text_engine.text_forward(self.text_model, input_ids, need_grad, ws, err=run.err)
                 if _TEXT_FORK_MARK and where >= 0:
                     fk.mark()
                     return body
@@ -757,10 +773,20 @@ class MultimodalSentimentModel(nn.Module):
             t_feat, run.text = box["out"]
             box["fork"].join()
         elif self.modality == "audio":
+            if run.err is not None:
+                label_check()
+                # (no text branch to carry the flag to the host: the copies it would make)
+                probe, host = ws.objs.get("text.err_probe"), ws.objs.get("text.err_host")
+                if probe is not None:
+                    probe[0].copy_(run.err, non_blocking=True)
+                    probe[1].record()
+                if host is not None:
+                    host.copy_(run.err, non_blocking=True)
             a_feat, run.audio = audio_engine.audio_forward(self.audio_model, audio, run.audio_training,
                                                            need_grad, ws)
         else:
-            t_feat, run.text = text_engine.text_forward(self.text_model, input_ids, need_grad, ws)
+            label_check()
+            t_feat, run.text = text_engine.text_forward(self.text_model, input_ids, need_grad, ws, err=run.err)
         seed = self._next_seed() if training and self._drop_p() > 0 else 0
         if self.modality == "both":
             if keep is None:
@@ -902,6 +928,9 @@ class MultimodalSentimentModel(nn.Module):
         lab = None
         if labels is not None:
             lab = labels.contiguous().to(torch.int64)
+            flag = torch.zeros(1, dtype=torch.int32, device=logits.device)
+            ops.check_labels(lab, ncls, flag)
+            text_engine.check_ids(flag)              # IndexError for a label outside the classes (synchronises)
         ops.softmax_ce(logits, lab, probs, ce, None)
         if labels is not None:
             loss = ce

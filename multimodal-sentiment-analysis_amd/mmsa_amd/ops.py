@@ -961,6 +961,12 @@ def param_norms(flat, table, tnorm, sum_out, chunk_sums_ready=False):
               int(chunk_sums_ready), _stream())
 
 
+def check_labels(labels, num_classes: int, err):
+    """Raises bit 1 of the sticky flag ``err`` (int32[1]) if a label lies outside [0, num_classes)."""
+    _lib.call("mmsa_check_labels", _chk(labels, torch.int64, "labels"), labels.numel(), int(num_classes),
+              _chk(err, torch.int32, "err"), _stream())
+
+
 def l2_grad_add(gflat, pflat, tnorm, lam, table, scale=None):
     """gflat += lam * scale * p / ||p|| per tensor; ``scale``: optional one-element device tensor."""
     _lib.call("mmsa_l2_grad_add", _chk(gflat), _chk(pflat), _chk(tnorm), float(lam), _opt(scale),

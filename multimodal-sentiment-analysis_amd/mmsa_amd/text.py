@@ -13,7 +13,7 @@ from . import ops
 from .workspace import Grads, Workspace
 
 
-def text_forward(m, input_ids: torch.Tensor, need_grad: bool, ws: Workspace):
+def text_forward(m, input_ids: torch.Tensor, need_grad: bool, ws: Workspace, err=None):
     if input_ids.dim() != 2:
         raise ValueError("input_ids must be [B, L]")
     ids = input_ids.contiguous()
@@ -35,7 +35,7 @@ def text_forward(m, input_ids: torch.Tensor, need_grad: bool, ws: Workspace):
     st.emb = ws.buf("text.emb", (B, L, E))
     # sticky flag: set by the gather / the backward scatter when a token id has no row in the table (a persistent
     # workspace creates it zeroed once; check_ids reads and clears it)
-    st.err = ws.buf("text.err", 1, torch.int32, zero=not ws.persistent)
+    st.err = err if err is not None else ws.buf("text.err", 1, torch.int32, zero=not ws.persistent)
     ops.embedding_gather(ids, table, st.emb, st.err)
     probe = ws.objs.get("text.err_probe")
     if probe is not None:
@@ -78,21 +78,41 @@ def text_forward(m, input_ids: torch.Tensor, need_grad: bool, ws: Workspace):
     return st.feat, st
 
 
-def check_ids(err: torch.Tensor):
-    """Raises what ``nn.Embedding`` raises in the reference (multimodal_model.py:179) when a token id was outside
-    the table.  Reads one int from the device (synchronises)."""
-    if int(err.item()):
-        err.zero_()
+def _raise_for(flag: int):
+    """The sticky flag word: bit 0 a token id outside the embedding table (``nn.Embedding`` raises this IndexError in
+    the reference, multimodal_model.py:179), bit 1 a class label outside [0, C) (``nn.CrossEntropyLoss``,
+    multimodal_model.py:452-454)."""
+    if flag & 1:
         raise IndexError("index out of range in self")
+    if flag & 2:
+        raise IndexError("Target is out of bounds.")
+
+
+def check_ids(err: torch.Tensor):
+    """Raises what the reference raises when a token id was outside the table or a label outside the classes.  Reads
+    one int from the device (synchronises) and clears it."""
+    flag = int(err.item())
+    if flag:
+        err.zero_()
+        _raise_for(flag)
 
 
 def check_ids_probe(probe):
-    """The same from the copy that text_forward left in pinned host memory behind the gather (``probe``: the pinned
-    int and the event recorded behind its copy).  Waits for the gather only."""
+    """The same from the copy that the forward pass left in pinned host memory behind the gather (``probe``: the pinned
+    int and the event recorded behind its copy).  Waits for the head of the forward pass only."""
     probe[1].synchronize()
-    if int(probe[0][0]):
+    flag = int(probe[0][0])
+    if flag:
         probe[0].zero_()
-        raise IndexError("index out of range in self")
+        _raise_for(flag)
+
+
+def check_labels_host(labels: torch.Tensor, num_classes: int):
+    """The label check for labels that are still in host memory (no device round trip)."""
+    if labels.numel():
+        lo, hi = int(labels.min()), int(labels.max())
+        if lo < 0 or hi >= num_classes:
+            raise IndexError(f"Target {lo if lo < 0 else hi} is out of bounds.")
 
 
 def check_ids_host(input_ids: torch.Tensor, vocab: int):

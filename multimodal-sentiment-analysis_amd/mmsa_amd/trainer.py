@@ -70,7 +70,7 @@ class TrainStep:
         self.ws = Workspace(dev, persistent=True)
         self.frontend = frontend
         self._err_host = None
-        if model.text_model is not None and dev.type == "cuda":
+        if dev.type == "cuda":
             self._err_host = torch.zeros(1, dtype=torch.int32).pin_memory()
             self.ws.objs["text.err_host"] = self._err_host
         self.keep = torch.ones(2, dtype=torch.float32, device=dev)
@@ -307,12 +307,14 @@ class TrainStep:
         # flag).  Every step copies that flag to pinned host memory, so the host sees it without waiting for the GPU:
         # the IndexError comes at the start of the first step() that finds the copy of an offending step landed
         # (normally the next one or the one after), and from check_ids() / state_dict(), which synchronise
+        # (class labels outside [0, C) likewise: nn.CrossEntropyLoss raises IndexError in the reference)
         self._nstep += 1
-        if ins["input_ids"] is not None:
-            if not ins["input_ids"].is_cuda:
-                text_engine.check_ids_host(ins["input_ids"], model.text_model.embedding.num_embeddings)
-            elif (self._err_host is not None and int(self._err_host[0])) or self._nstep % self.CHECK_EVERY == 0:
-                self.check_ids()
+        if ins["input_ids"] is not None and not ins["input_ids"].is_cuda:
+            text_engine.check_ids_host(ins["input_ids"], model.text_model.embedding.num_embeddings)
+        if not labels.is_cuda:
+            text_engine.check_labels_host(labels, model.classifier[len(model.classifier) - 1].weight.shape[0])
+        if (self._err_host is not None and int(self._err_host[0])) or self._nstep % self.CHECK_EVERY == 0:
+            self.check_ids()
         for k, t in ins.items():
             if t is not None:
                 want = torch.int64 if k in ("input_ids", "labels") else torch.float32
@@ -433,12 +435,12 @@ class TrainStep:
 
     def check_ids(self):
         """Raises IndexError if any step since the last call saw a token id outside the embedding table (those
-        tokens contributed zero rows and no gradient).  Synchronises."""
-        if self.model.text_model is not None:
-            if self._err_host is not None:
-                torch.cuda.synchronize(self.arena.device)
-                self._err_host.zero_()
-            text_engine.check_ids(self.ws.buf("text.err", 1, torch.int32))
+        tokens contributed zero rows and no gradient) or a class label outside [0, C) (those rows contributed no loss
+        term).  Synchronises."""
+        if self._err_host is not None:
+            torch.cuda.synchronize(self.arena.device)
+            self._err_host.zero_()
+        text_engine.check_ids(self.ws.buf("text.err", 1, torch.int32))
 
     @torch.no_grad()
     def grad_norm(self) -> torch.Tensor:

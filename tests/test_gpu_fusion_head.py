@@ -151,7 +151,7 @@ def test_other_widths_and_batch_sizes_match_oracle(td, ad, fd, nc, B):
     np.testing.assert_allclose(out["logits"].detach().cpu().numpy(), ref["logits"].detach().numpy(), rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(out["attention_weights"].detach().cpu().numpy(), ref["attention_weights"].detach().numpy(),
                                rtol=2e-4, atol=1e-6)
-    assert abs(float(out["loss"].detach()) - float(ref["loss"])) < 2e-5
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) < 2e-5
     pairs = [(k, p.grad, w[k].grad) for k, p in m.named_parameters()] + [("text", tg.grad, tr.grad), ("audio", ag.grad, ar.grad)]
     for k, gg, r in pairs:
         gg = gg.detach().cpu().double()

@@ -737,3 +737,41 @@ def test_train_step_refuses_a_model_whose_parameters_moved_away():
                 before = m._arena.flat.clone()
                 ts2.step(**_step_inputs("both", b))
                 assert not torch.equal(before, m._arena.flat)
+
+
+@pytest.mark.parametrize("modality", ["audio", "text", "both"])
+def test_class_label_outside_the_classes_raises(modality):
+    """nn.CrossEntropyLoss refuses a target outside [0, C) (multimodal_model.py:452-454; the classic slip in this task
+    is to pass sentiments as -1 / 0 / 1).  The loss kernels would treat such a row as one without a target: a small
+    launch at the head of the pass raises a flag instead, which becomes the reference's IndexError -- at once in the
+    eager forward (with or without gradients), at the next check in TrainStep."""
+    from mmsa_amd.trainer import TrainStep
+    m = seeded_model(modality, vocab=SMALL_VOCAB).to(DEV).train()
+    b = batch_tensors(0, 8, vocab=SMALL_VOCAB, device=DEV)
+    kw = model_inputs(modality, b)
+    for bad_value in (-1, 3):
+        bad = b["label"].clone()
+        bad[5] = bad_value
+        with pytest.raises(IndexError, match="out of bounds"):
+            m(**kw, labels=bad)
+        with pytest.raises(IndexError, match="out of bounds"):
+            m(**kw, labels=bad.cpu())
+        with pytest.raises(IndexError, match="out of bounds"), torch.no_grad():
+            m(**kw, labels=bad)
+    out = m(**kw, labels=b["label"])                          # the flag does not outlive the call that raised
+    assert bool(torch.isfinite(out["loss"]))
+    for use_graph in (False, True):
+        ts = TrainStep(m, use_graph=use_graph)
+        for _ in range(4):
+            ts.step(**_step_inputs(modality, b))
+        with pytest.raises(IndexError, match="out of bounds"):
+            ts.step(**{**_step_inputs(modality, b), "labels": bad.cpu()})      # host-resident: before any launch
+        ts.step(**{**_step_inputs(modality, b), "labels": bad})
+        with pytest.raises(IndexError, match="out of bounds"):
+            ts.state_dict()
+        ts.step(**{**_step_inputs(modality, b), "labels": bad})
+        torch.cuda.synchronize()
+        with pytest.raises(IndexError, match="out of bounds"):
+            ts.step(**_step_inputs(modality, b))                                 # the pinned copy has landed
+        ts.step(**_step_inputs(modality, b))
+        ts.state_dict()
