@@ -213,6 +213,13 @@ class HybridFusionHead(nn.Module):
             labels = labels.to(dev)
             if labels.dim() == 1 and labels.dtype != torch.long:
                 labels = (labels + 1).long()
+            # nn.CrossEntropyLoss (early_fusion.py:346) refuses a target outside the classes; the loss kernel would
+            # treat the row as one without a target.  (One read from the device: this head is a few launches on eight
+            # rows, and the reference's loop reads the loss after every step anyway.)
+            if labels.numel():
+                lo, hi = int(labels.min()), int(labels.max())
+                if lo < 0 or hi >= self.classifier[-1].weight.shape[0]:
+                    raise IndexError(f"Target {lo if lo < 0 else hi} is out of bounds.")
         fl = self.fusion_layer
         if _needs_grad(self) or (torch.is_grad_enabled() and (t.requires_grad or a.requires_grad)):
             params = list(fl.parameters()) + list(self.classifier.parameters())

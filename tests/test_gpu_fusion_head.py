@@ -123,6 +123,12 @@ def test_eval_and_layer_alone():
     m.train()                      # dropout active: runs, differs from eval, stays finite
     o2 = m(t.to(DEV), a.to(DEV))
     assert torch.isfinite(o2["logits"]).all()
+    # a class label outside the classes: the reference's CrossEntropyLoss raises, so does the head (float labels are
+    # sentiments -1 / 0 / 1 and are shifted first, early_fusion.py:341-345)
+    for bad in (torch.tensor([0, 1, 3, 2, 0]), torch.tensor([0, -1, 1, 2, 0]), torch.tensor([0., 2., 1., -1., 0.])):
+        with pytest.raises(IndexError, match="out of bounds"):
+            m(t.to(DEV), a.to(DEV), labels=bad.to(DEV))
+    assert m(t.to(DEV), a.to(DEV), labels=torch.tensor([-1., 0., 1., 1., 0.]).to(DEV))["loss"] is not None
 
 
 @pytest.mark.gpu
