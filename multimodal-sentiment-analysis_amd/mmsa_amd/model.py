@@ -703,13 +703,31 @@ class MultimodalSentimentModel(nn.Module):
         self.__dict__["_seed_counter"] = self.__dict__.get("_seed_counter", 0) + 1
         return (torch.initial_seed() * 1000003 + self._seed_counter * 97) & ((1 << 62) - 1)
 
-    def _check_inputs(self, audio, input_ids):
+    def _check_inputs(self, audio, input_ids, labels=None, audio_dims=(3, 4)):
+        """The reference's three ValueErrors (multimodal_model.py:419-435), and what its torch layers would complain
+        about further down: the kernels take the batch size from one input and trust the others to match, so rows
+        that are not there must be refused here, on the host."""
         if self.modality == "audio" and audio is None:
             raise ValueError("Audio input is required for audio modality")
         if self.modality == "text" and input_ids is None:
             raise ValueError("Text input is required for text modality")
         if self.modality == "both" and (audio is None or input_ids is None):
             raise ValueError("Both audio and text inputs are required for multimodal fusion")
+        B = None
+        if self.modality != "text":
+            if audio.dim() not in audio_dims:
+                raise ValueError(f"audio input has {audio.dim()} dimensions, expected {' or '.join(map(str, audio_dims))}")
+            B = audio.shape[0]
+        if self.modality != "audio":
+            if input_ids.dim() != 2:
+                raise ValueError("input_ids must be [batch, tokens]")
+            if B is not None and input_ids.shape[0] != B:
+                raise ValueError(f"audio holds {B} utterances, input_ids {input_ids.shape[0]}")
+            B = input_ids.shape[0]
+        if B == 0:
+            raise ValueError("empty batch")
+        if labels is not None and (labels.dim() != 1 or labels.shape[0] != B):
+            raise ValueError(f"labels must be [{B}] (one class index per utterance), got {tuple(labels.shape)}")
 
     def _run(self, audio, input_ids, labels, drops, need_grad, ws, keep=None, logits_out=None, norms_ready=False,
              grad_scale=1.0, step_state=None):
@@ -872,7 +890,7 @@ class MultimodalSentimentModel(nn.Module):
 
     # ------------------------------------------------------------------ the reference's forward signature
     def forward(self, audio=None, input_ids=None, attention_mask=None, labels=None):
-        self._check_inputs(audio, input_ids)
+        self._check_inputs(audio, input_ids, labels)
         arena = self._ensure_arena()
         # kernels are launched on the current device: make that the model's for the duration of the call (a model moved
         # to cuda:1 in a process that never called torch.cuda.set_device)

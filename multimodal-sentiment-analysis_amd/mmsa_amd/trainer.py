@@ -301,7 +301,8 @@ class TrainStep:
             ins["audio"] = ins["wave"] = None
         if model.modality == "audio":
             ins["input_ids"] = None
-        model._check_inputs(ins["audio"] if ins["wave"] is None else ins["wave"], ins["input_ids"])
+        model._check_inputs(ins["audio"] if ins["wave"] is None else ins["wave"], ins["input_ids"], labels,
+                            audio_dims=(3, 4) if ins["wave"] is None else (2,))
         # a token id outside the embedding table raises IndexError in the reference.  Ids that arrive in host memory
         # are checked here; device-resident ids are checked by the kernels (they skip such tokens and raise a sticky
         # flag).  Every step copies that flag to pinned host memory, so the host sees it without waiting for the GPU:

@@ -558,3 +558,24 @@ def test_what_the_fused_model_cannot_honour_is_refused_not_ignored():
     assert g.grad_fn is None                               # no graph hangs on the gradient: a penalty on it cannot be
     with pytest.raises(RuntimeError, match="does not require grad|once_differentiable"):     # differentiated, and says so
         g.square().sum().backward()
+
+
+def test_inputs_whose_batch_sizes_disagree_are_refused_on_the_host():
+    """The kernels take the batch size from one input and trust the others to have as many rows; torch's layers would
+    have raised on the mismatch further down.  Refused before any launch, in the model and in TrainStep."""
+    from mmsa_amd.trainer import TrainStep
+    m = seeded_model("both", vocab=SMALL_VOCAB).to(DEV).train()
+    b = batch_tensors(3, 8, vocab=SMALL_VOCAB, device=DEV)
+    ts = TrainStep(m)
+    for kw in (dict(audio=b["audio"], input_ids=b["input_ids"][:6], labels=b["label"]),
+               dict(audio=b["audio"][:5], input_ids=b["input_ids"], labels=b["label"]),
+               dict(audio=b["audio"], input_ids=b["input_ids"], labels=b["label"][:7]),
+               dict(audio=b["audio"], input_ids=b["input_ids"][0], labels=b["label"]),
+               dict(audio=b["audio"][:0], input_ids=b["input_ids"][:0], labels=b["label"][:0]),
+               dict(audio=b["audio"], input_ids=b["input_ids"], labels=b["label"][:, None])):
+        with pytest.raises(ValueError):
+            m(**kw)
+        with pytest.raises(ValueError):
+            ts.step(**kw)
+    m(audio=b["audio"], input_ids=b["input_ids"], labels=b["label"])
+    ts.step(audio=b["audio"], input_ids=b["input_ids"], labels=b["label"])
