@@ -579,3 +579,37 @@ def test_inputs_whose_batch_sizes_disagree_are_refused_on_the_host():
             ts.step(**kw)
     m(audio=b["audio"], input_ids=b["input_ids"], labels=b["label"])
     ts.step(audio=b["audio"], input_ids=b["input_ids"], labels=b["label"])
+
+
+@pytest.mark.parametrize("modality", ["audio", "text", "both"])
+@pytest.mark.parametrize("with_labels", [False, True])
+def test_a_loss_of_the_callers_own_on_logits_and_probabilities(modality, with_labels):
+    """The reference's driver builds a class-weighted / focal criterion (multimodal_train.py:470-478) that a caller may
+    apply to ``outputs["logits"]`` instead of, or on top of, the model's own loss: gradients arriving at the logits and
+    at the probabilities flow back through the same HIP backward pass.  Against the float64 oracle with the same loss."""
+    from mmsa_amd.model import FocalLoss
+    m = seeded_model(modality, vocab=SMALL_VOCAB).to(DEV).train()
+    if modality == "both":
+        m.fusion_layer.draw_modality_dropout = lambda: (False, False)
+    sd = {k: v.detach().cpu().double() for k, v in m.state_dict().items()}
+    b = batch_tensors(41, 8, vocab=SMALL_VOCAB)
+    bd = {k: v.to(DEV) for k, v in b.items()}
+    weights = torch.tensor([0.5, 2.0, 1.0])
+
+    def user_loss(out, y, w):
+        ce = torch.nn.functional.cross_entropy(out["logits"], y, weight=w.to(out["logits"]))
+        total = ce + 0.3 * FocalLoss()(out["logits"], y) + 0.2 * out["probabilities"][:, 0].square().sum()
+        return total + 0.5 * out["loss"] if out["loss"] is not None else total
+
+    out = m(**model_inputs(modality, bd), labels=bd["label"] if with_labels else None)
+    assert (out["loss"] is not None) == with_labels
+    user_loss(out, bd["label"], weights).backward()
+    w = model_ref.clone_state(sd, requires_grad=True)
+    ref = model_ref.forward(w, modality, b["audio"].double() if modality != "text" else None,
+                            b["input_ids"] if modality != "audio" else None, b["label"] if with_labels else None,
+                            training=True)
+    user_loss(ref, b["label"], weights.double()).backward()
+    for k, p in m.named_parameters():
+        r = w[k].grad if w[k].grad is not None else torch.zeros_like(w[k])
+        err = float(torch.linalg.vector_norm(p.grad.cpu().double() - r))
+        assert err <= 1e-3 * float(torch.linalg.vector_norm(r)) + 2e-5, f"{k}: {err:.2e}"
