@@ -163,6 +163,54 @@ def main():
         t = timeit(lambda: ts3.step(audio=spec32, input_ids=ids32, labels=lab32), reps=30, warm=5)
         out[f"trainstep_{'graph' if graph else 'eager'}_from_spectrograms_B32"] = {"ms": round(t * 1e3, 3),
                                                                                    "utt_per_s": round(32 / t)}
+    # config 4: the attention-fusion head on pooled features (text [8,128], audio [8,768]), the reference's loop
+    # (early_fusion.py:716-733: loss / 2, two micro-batches per update, clip 1.0 over the head, AdamW 1e-4 / 0.005)
+    from mmsa_amd.fusion_head import HybridFusionHead
+    torch.manual_seed(42)
+    fh = HybridFusionHead(128, 768, 512, 3, 0.3).to(DEV).train()
+    fopt = torch.optim.AdamW(fh.parameters(), lr=1e-4, weight_decay=0.005)
+    tf8, af8 = torch.randn(8, 128, device=DEV), torch.randn(8, 768, device=DEV)
+    y8 = torch.randint(0, 3, (8,), device=DEV)
+
+    def head_update():
+        fopt.zero_grad()
+        for _ in range(2):
+            (fh(tf8, af8, labels=y8)["loss"] / 2).backward()
+        torch.nn.utils.clip_grad_norm_(fh.parameters(), max_norm=1.0)
+        fopt.step()
+    t = timeit(head_update, reps=30, warm=5)
+    out["fusion_head_B8_accum2_update"] = {"ms": round(t * 1e3, 3), "utt_per_s": round(16 / t)}
+    # the same head assembled from stock torch layers on the same GPU (what the reference runs), same loop
+    nn = torch.nn
+
+    class StockHead(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.tp, self.ap = nn.Linear(128, 512), nn.Linear(768, 512)
+            self.tn, self.an = nn.LayerNorm(512), nn.LayerNorm(512)
+            self.att = nn.Sequential(nn.Linear(512, 256), nn.Tanh(), nn.Dropout(0.3), nn.Linear(256, 1))
+            self.gate = nn.Sequential(nn.Linear(1024, 512), nn.Sigmoid())
+            self.cls = nn.Sequential(nn.Linear(512, 256), nn.LayerNorm(256), nn.GELU(), nn.Dropout(0.3),
+                                     nn.Linear(256, 64), nn.LayerNorm(64), nn.GELU(), nn.Dropout(0.3), nn.Linear(64, 3))
+
+        def forward(self, t, a, labels):
+            tp, ap = self.tn(self.tp(t)), self.an(self.ap(a))
+            mod = torch.stack([tp, ap], dim=1)
+            w = torch.softmax(self.att(mod).squeeze(-1), dim=1)
+            wt, wa = tp * w[:, 0:1], ap * w[:, 1:2]
+            g = self.gate(torch.cat([wt, wa], dim=1))
+            return nn.functional.cross_entropy(self.cls(wt * g + wa * (1 - g)), labels)
+    sh = StockHead().to(DEV).train()
+    sopt = torch.optim.AdamW(sh.parameters(), lr=1e-4, weight_decay=0.005)
+
+    def stock_update():
+        sopt.zero_grad()
+        for _ in range(2):
+            (sh(tf8, af8, y8) / 2).backward()
+        torch.nn.utils.clip_grad_norm_(sh.parameters(), max_norm=1.0)
+        sopt.step()
+    t = timeit(stock_update, reps=30, warm=5)
+    out["fusion_head_B8_accum2_update_stock_torch_layers"] = {"ms": round(t * 1e3, 3), "utt_per_s": round(16 / t)}
     # inference, config 5: eval forward of 1024 utterances (front end included), predictions stay on the device
     model.eval()
     b = data.make_batch(0, 64, with_wave=True)
