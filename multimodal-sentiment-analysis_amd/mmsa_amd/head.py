@@ -268,6 +268,10 @@ def head_forward_audio(model, feat, labels, training, drop_p, seed, need_grad, w
     cl = model.classifier
     p = drop_p if training else 0.0
     step = step_state if p > 0 else None
+    if B == 1 and (cl[2].training or cl[6].training):
+        # what nn.BatchNorm1d says to a single row in training mode (multimodal_model.py:369-375): its variance is zero
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size "
+                         f"torch.Size([1, {cl[1].weight.shape[0]}])")
     # (the two BatchNorm1d layers go by their own flags, as in torch; dropout by the model's)
     st = SimpleNamespace(kind="audio", B=B, feat=feat, training=training, p=p, seed=seed, step=step,
                          bn_training=(cl[2].training, cl[6].training))

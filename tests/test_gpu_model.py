@@ -579,6 +579,13 @@ def test_inputs_whose_batch_sizes_disagree_are_refused_on_the_host():
             ts.step(**kw)
     m(audio=b["audio"], input_ids=b["input_ids"], labels=b["label"])
     ts.step(audio=b["audio"], input_ids=b["input_ids"], labels=b["label"])
+    # one utterance through the audio-only classifier in training mode: nn.BatchNorm1d refuses a single row
+    ma = seeded_model("audio").to(DEV).train()
+    with pytest.raises(ValueError, match="more than 1 value per channel"):
+        ma(audio=b["audio"][:1], labels=b["label"][:1])
+    ma.eval()
+    with torch.no_grad():
+        assert ma(audio=b["audio"][:1])["logits"].shape == (1, 3)
 
 
 @pytest.mark.parametrize("modality", ["audio", "text", "both"])
