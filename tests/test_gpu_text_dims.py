@@ -23,7 +23,8 @@ def _reference(weights, ids):
 
 
 CONFIGS = [(128, [2, 3], 64, 40, 6), (64, [3, 4, 5, 6, 7], 128, 33, 5), (256, [7], 192, 16, 3), (32, [3, 4, 5], 64, 128, 9),
-           (96, [2, 5, 7, 3], 64, 21, 4), (64, [2, 5, 7, 3], 64, 21, 4), (192, [3, 4, 5], 128, 128, 32)]
+           (96, [2, 5, 7, 3], 64, 21, 4), (64, [2, 5, 7, 3], 64, 21, 4), (192, [3, 4, 5], 128, 128, 32),
+           (256, [3, 4, 5], 128, 300, 4), (256, [3, 4, 5], 128, 1000, 2)]      # sequences longer than the reference's 128
 
 
 @pytest.mark.parametrize("E,sizes,nf,L,B", CONFIGS)
